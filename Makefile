@@ -1,0 +1,34 @@
+# Builds everything that runs on the GPU box, in-tree:
+#   raytracer_amd/lib/libhip_raytracer.so   the C ABI + gfx950 kernels   (make lib)
+#   raytracer_amd/bin/raytracer_hip         host CLI over the C ABI       (make host)
+#   oracle/_build, oracle/_ref              test-only checkers            (make oracle)
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+# -ffp-contract=off: fusion happens only where the source asks for it (exact vs fast paths)
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude
+HOSTCXX  ?= /opt/rocm/lib/llvm/bin/clang++
+HOSTFLAGS := -std=c++20 -O2 -Wall -Wextra -pedantic -Werror -Iinclude -Iraytracer_amd/host
+
+LIB := raytracer_amd/lib/libhip_raytracer.so
+CLI := raytracer_amd/bin/raytracer_hip
+HOST_SRCS := $(wildcard raytracer_amd/host/*.cpp)
+
+.PHONY: all lib host oracle clean
+all: lib host oracle
+
+lib: $(LIB)
+$(LIB): raytracer_amd/csrc/hip_raytracer_kernels.hip include/hip_raytracer.h
+	@mkdir -p raytracer_amd/lib
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $<
+
+host: $(CLI)
+$(CLI): $(HOST_SRCS) $(wildcard raytracer_amd/host/*.h) include/hip_raytracer.h $(LIB)
+	@mkdir -p raytracer_amd/bin
+	$(HOSTCXX) $(HOSTFLAGS) $(HOST_SRCS) -Lraytracer_amd/lib -lhip_raytracer -Wl,-rpath,'$$ORIGIN/../lib' -lpthread -o $@
+
+oracle:
+	$(MAKE) -C oracle all
+
+clean:
+	rm -rf raytracer_amd/lib raytracer_amd/bin
+	$(MAKE) -C oracle clean

@@ -1,0 +1,133 @@
+/*
+ * hip_raytracer.h -- C ABI of the MI355X (gfx950) rendering backend.
+ *
+ * This is the boundary a host program binds: plain C, POD arguments, no C++ or torch types.
+ * The reference's backends are C++ classes behind `ae::raytracer`
+ * (src/raytracer.h:11-33: ctor(u32 *framebuffer), `bool setup()`, `void trace()`), with the GPU
+ * one adding static `init()` / `terminate()` (src/vulkan_raytracer.h:13-20).  Each entry point
+ * below names the member it stands behind; `ae::hip_raytracer` (raytracer_amd/host/) is the thin
+ * C++ class that forwards to them.
+ *
+ * Conventions: every function returning int returns AEHIP_OK (0) or a negative AEHIP_E_* code
+ * and never throws; aehip_last_error() gives the message for the calling thread's last failure.
+ * A backend object is used from one thread at a time (the reference calls setup()/trace() once
+ * from its main thread, src/main.cpp:27-59).
+ */
+#ifndef AE_HIP_RAYTRACER_H
+#define AE_HIP_RAYTRACER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AEHIP_OK              0
+#define AEHIP_E_NO_DEVICE    -1   /* no usable HIP device / runtime failure at init        */
+#define AEHIP_E_INVALID      -2   /* bad argument (null pointer, zero size, bad band, ...) */
+#define AEHIP_E_HIP          -3   /* a HIP runtime call failed; see aehip_last_error()     */
+#define AEHIP_E_NOT_SETUP    -4   /* trace before a successful setup                        */
+#define AEHIP_E_TOO_LARGE    -5   /* size beyond what an entry point supports               */
+
+/* Surface response of a sphere. */
+enum {
+    AEHIP_MAT_NORMAL     = 0,  /* the reference's shading: colour = remap(normal), path ends
+                                  (src/software_raytracer.cpp:227-234)                      */
+    AEHIP_MAT_LAMBERT    = 1,  /* diffuse, albedo                                            */
+    AEHIP_MAT_METAL      = 2,  /* mirror + param = fuzz radius                               */
+    AEHIP_MAT_DIELECTRIC = 3   /* param = index of refraction, Schlick reflectance           */
+};
+
+enum {
+    AEHIP_FLAG_JITTER     = 1u,  /* sample position drawn inside the pixel; off = pixel centre
+                                    (src/software_raytracer.cpp:218)                         */
+    AEHIP_FLAG_FAST       = 2u,  /* fused multiply-add and hardware reciprocal / rsqrt; off =
+                                    IEEE fp32 in the reference's operation order             */
+    AEHIP_FLAG_COUNT_RAYS = 4u   /* count ray segments on the device (aehip_stats.rays)      */
+};
+
+enum {
+    AEHIP_PASS_PRIMARY = 0,  /* the reference's pass: sphere 0 only, nearest root, no range
+                                test, one ray at the pixel centre (src/shapes.cpp:14-30)     */
+    AEHIP_PASS_PATH    = 1   /* shape list + closest hit, materials, spp, bounce loop        */
+};
+
+/* 48 bytes.  center/radius mirror ae::sphere (src/shapes.h:10-19); radius is used as |radius|
+ * (src/shapes.cpp:10-12). */
+typedef struct aehip_sphere {
+    float    center[3];
+    float    radius;
+    float    albedo[3];
+    float    param;
+    uint32_t material;
+    uint32_t reserved[3];
+} aehip_sphere;
+
+/* The four scene globals of ae::raytracer (src/raytracer.h:16-19, src/raytracer.cpp:10-13),
+ * with the single sphere generalised to a list. */
+typedef struct aehip_scene {
+    float    background0[4];   /* r,g,b,a : colour at image row 0    */
+    float    background1[4];   /* r,g,b,a : colour towards row H     */
+    float    camera_pos[4];    /* x,y,z,0                            */
+    uint32_t sphere_count;
+    uint32_t reserved;
+    const aehip_sphere *spheres;   /* host memory, copied by setup */
+} aehip_scene;
+
+typedef struct aehip_params {
+    uint32_t width, height;         /* what raytracer::get_resolution() returns (src/raytracer.cpp:18-34) */
+    uint32_t row_begin, row_count;  /* band of image rows this backend renders; row_count 0 = all rows.
+                                       Outputs hold row_count rows, first row = row_begin. */
+    uint32_t spp;                   /* samples per pixel, >= 1 */
+    uint32_t max_depth;             /* ray segments per path, >= 1 */
+    uint32_t seed;
+    uint32_t flags;                 /* AEHIP_FLAG_* */
+    uint32_t pass;                  /* AEHIP_PASS_* */
+    uint32_t reserved[3];
+} aehip_params;
+
+typedef struct aehip_stats {
+    float    kernel_ms;     /* device time of the last trace's kernel(s), from HIP events */
+    float    copy_ms;       /* device->host copy of the last aehip_backend_trace           */
+    uint64_t rays;          /* ray segments (only with AEHIP_FLAG_COUNT_RAYS)              */
+    uint64_t paths;         /* width * rows * spp of the last trace                        */
+    uint32_t vgprs, sgprs, lds_bytes, reserved;   /* resource use of the kernel last launched */
+} aehip_stats;
+
+typedef struct aehip_backend aehip_backend;
+
+/* stands behind vulkan_raytracer::init() (src/vulkan_raytracer.h:13): loads the runtime, counts
+ * gfx950 devices.  Returns AEHIP_OK when at least one device is usable. */
+int aehip_init(void);
+/* stands behind vulkan_raytracer::terminate() (src/vulkan_raytracer.h:14; called unconditionally
+ * at exit, src/main.cpp:21): safe without a prior init. */
+void aehip_terminate(void);
+int aehip_device_count(void);
+const char *aehip_last_error(void);
+
+/* stands behind the backend constructor `raytracer(u32 *buffer)` (src/raytracer.cpp:15-16).
+ * `framebuffer` is borrowed host memory for width*row_count packed 0xAARRGGBB words; it may be
+ * NULL for a backend that is only ever traced into device memory. */
+int aehip_backend_create(int device, uint32_t *framebuffer, aehip_backend **out);
+void aehip_backend_destroy(aehip_backend *backend);
+
+/* stands behind `bool setup()` (src/raytracer.h:25; CPU version src/software_raytracer.cpp:68-91):
+ * validates the request, derives the viewport, uploads the scene, sizes device buffers. */
+int aehip_backend_setup(aehip_backend *backend, const aehip_scene *scene, const aehip_params *params);
+
+/* stands behind `void trace()` (src/raytracer.h:26; called at src/main.cpp:55): renders and
+ * copies the band into the borrowed framebuffer; the image is complete when it returns. */
+int aehip_backend_trace(aehip_backend *backend);
+
+/* Same render, outputs left in device memory (for callers that keep the image on the GPU or
+ * gather bands across GPUs): argb_dev = width*row_count u32; rgba_dev (nullable) =
+ * width*row_count float4 holding the averaged colour before quantisation.  Asynchronous on
+ * `hip_stream` (a hipStream_t; NULL = the backend's own stream, which the call then waits on). */
+int aehip_backend_trace_device(aehip_backend *backend, uint32_t *argb_dev, float *rgba_dev, void *hip_stream);
+
+int aehip_backend_stats(aehip_backend *backend, aehip_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AE_HIP_RAYTRACER_H */

@@ -1,0 +1,818 @@
+// hip_raytracer_kernels.hip -- gfx950 kernels and the C ABI of include/hip_raytracer.h.
+//
+// Built with -ffp-contract=off: the compiler never fuses a multiply into an add on its own.
+// "Exact" code paths therefore evaluate IEEE binary32 expressions in the order written, with
+// correctly rounded division and square root, and reproduce the reference's CPU results bit for
+// bit; "fast" code paths ask for fusion and hardware approximations explicitly (rt_fma, rt_rcp,
+// rt_rsq below).
+//
+// Reference functions restated here (paths relative to the reference checkout):
+//   viewport set-up            src/software_raytracer.cpp:68-91
+//   primary ray                src/software_raytracer.cpp:218-221, src/ray.h:18-20
+//   normalise                  src/vec.h:140-166
+//   ray-sphere intersection    src/shapes.cpp:14-30
+//   normal -> colour           src/aemath.h:34-42, src/software_raytracer.cpp:227-232
+//   row gradient background    src/aemath.h:24-26, src/software_raytracer.cpp:210-215
+//   colour -> 0xAARRGGBB       src/color.cpp:96-105
+//   framebuffer layout         src/software_raytracer.cpp:94-108
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "hip_raytracer.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// launch constants
+// ------------------------------------------------------------------------------------------
+
+constexpr int kTileW = 16;               // path pass: a 256-thread workgroup covers 16x16 pixels,
+constexpr int kTileH = 16;               // each wave64 a 16x4 strip (coherent rays, 64-B row segments)
+constexpr int kBlock = kTileW * kTileH;
+constexpr int kLdsSpheres = 2048;        // shape-list chunk staged in LDS: 2048 x 16 B = 32 KiB
+constexpr int kPrimaryBlock = 256;       // primary pass: 256 threads x 4 pixels each
+constexpr float kTMin = 0.001f;
+
+struct view_consts {
+    float vw_half, vh_half;     // viewport_size * 0.5 (exact: power-of-two scale)
+    float psx, psy;             // pixel size on the viewport plane
+    float cam[3];
+    float bg0[3];
+    float bg1[3];
+    uint32_t width, height;
+    uint32_t row_begin, row_count;
+    uint32_t spp, max_depth;
+    uint32_t seed_hash;         // pcg_hash(seed), hoisted to the host
+    uint32_t flags;
+    uint32_t n_spheres;
+};
+
+struct f3 {
+    float x, y, z;
+};
+
+// ------------------------------------------------------------------------------------------
+// arithmetic policy
+// ------------------------------------------------------------------------------------------
+
+template <bool EXACT>
+__device__ __forceinline__ float rt_fma(float a, float b, float c) {
+    if constexpr(EXACT) return a * b + c;            // two roundings (contraction is off)
+    else return __builtin_fmaf(a, b, c);
+}
+
+template <bool EXACT>
+__device__ __forceinline__ float rt_div(float a, float b) {
+    if constexpr(EXACT) return a / b;                // correctly rounded (v_div_scale/fmas/fixup)
+    else return a * __builtin_amdgcn_rcpf(b);
+}
+
+template <bool EXACT>
+__device__ __forceinline__ float rt_sqrt(float a) {
+    if constexpr(EXACT) return __builtin_sqrtf(a);   // correctly rounded
+    else return __builtin_amdgcn_sqrtf(a);
+}
+
+template <bool EXACT>
+__device__ __forceinline__ float dot3(f3 a, f3 b) {
+    if constexpr(EXACT) return (a.x * b.x + a.y * b.y) + a.z * b.z;
+    else return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x));
+}
+
+// src/vec.h:155-160: divide each lane by the length unless the length is zero
+template <bool EXACT>
+__device__ __forceinline__ f3 normalize3(f3 v) {
+    if constexpr(EXACT) {
+        const float n = __builtin_sqrtf((v.x * v.x + v.y * v.y) + v.z * v.z);
+        if(n != 0.0f) {
+            v.x = v.x / n;
+            v.y = v.y / n;
+            v.z = v.z / n;
+        }
+        return v;
+    } else {
+        const float m = dot3<false>(v, v);
+        const float inv = m > 0.0f ? __builtin_amdgcn_rsqf(m) : 0.0f;
+        return f3{v.x * inv, v.y * inv, v.z * inv};
+    }
+}
+
+// src/aemath.h:24-26
+template <bool EXACT>
+__device__ __forceinline__ float lerp1(float t, float v0, float v1) {
+    if constexpr(EXACT) return (1.0f - t) * v0 + (t * v1);
+    else return __builtin_fmaf(1.0f - t, v0, t * v1);
+}
+
+// src/aemath.h:34-42 with ranges (-1,1) -> (0,1): 0 + (v + 1) * 1 / 2; the *1, /2 and 0+ are
+// value-preserving, so (v + 1) * 0.5 is the same float
+__device__ __forceinline__ float remap_unit(float v) { return (v + 1.0f) * 0.5f; }
+
+// src/color.cpp:96-105: truncate towards zero, alpha is the constant 1.0f * 255.0f
+__device__ __forceinline__ uint32_t pack_argb32(float r, float g, float b) {
+    return (255u << 24) | (static_cast<uint32_t>(r * 255.0f) << 16) |
+           (static_cast<uint32_t>(g * 255.0f) << 8) | (static_cast<uint32_t>(b * 255.0f) & 0xffu);
+}
+
+__device__ __forceinline__ float clamp01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
+
+// src/software_raytracer.cpp:218-221 + src/ray.h:18-20
+template <bool EXACT>
+__device__ __forceinline__ f3 primary_direction(const view_consts &vc, float px, float py) {
+    const float uvx = rt_fma<EXACT>(px, vc.psx, -vc.vw_half);
+    const float uvy = rt_fma<EXACT>(py, vc.psy, -vc.vh_half);
+    const f3 d = {uvx - vc.cam[0], uvy - vc.cam[1], 0.0f - vc.cam[2]};
+    return normalize3<EXACT>(d);
+}
+
+// src/software_raytracer.cpp:210-215
+template <bool EXACT>
+__device__ __forceinline__ f3 row_background(const view_consts &vc, uint32_t y) {
+    const float t = rt_div<EXACT>(static_cast<float>(y), static_cast<float>(vc.height));
+    return f3{lerp1<EXACT>(t, vc.bg0[0], vc.bg1[0]), lerp1<EXACT>(t, vc.bg0[1], vc.bg1[1]),
+              lerp1<EXACT>(t, vc.bg0[2], vc.bg1[2])};
+}
+
+// ------------------------------------------------------------------------------------------
+// counter-based per-path random stream (replaces the stateful xorshift of src/random.cpp:18-29)
+// ------------------------------------------------------------------------------------------
+
+__host__ __device__ __forceinline__ uint32_t pcg_permute(uint32_t s) {
+    const uint32_t w = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+    return (w >> 22) ^ w;
+}
+__host__ __device__ __forceinline__ uint32_t pcg_hash(uint32_t v) { return pcg_permute(v * 747796405u + 2891336453u); }
+
+// key of path (pixel, sample): a pure function of absolute pixel index, sample index and seed
+__device__ __forceinline__ uint32_t path_key(uint32_t seed_hash, uint32_t pixel, uint32_t sample) {
+    return pcg_hash(pixel + pcg_hash(sample + seed_hash));
+}
+__device__ __forceinline__ uint32_t rng_next(uint32_t &state) {
+    state = state * 747796405u + 2891336453u;
+    return pcg_permute(state);
+}
+
+// cos, sin of 2*pi*u, u in [0,1): octant reduction + Taylor polynomials on [0, pi/4], built from
+// + and * only so the exact build reproduces the CPU checker's bits
+template <bool EXACT>
+__device__ __forceinline__ void cossin_2pi(float u, float &c_out, float &s_out) {
+    const float k = u * 8.0f;
+    int oct = static_cast<int>(k);
+    oct = oct > 7 ? 7 : oct;
+    const float f = k - static_cast<float>(oct);
+    const float g = (oct & 1) ? (1.0f - f) : f;
+    const float x = g * 0.78539816339744830962f;
+    const float x2 = x * x;
+
+    float p = -1.0f / 5040.0f;
+    p = rt_fma<EXACT>(p, x2, 1.0f / 120.0f);
+    p = rt_fma<EXACT>(p, x2, -1.0f / 6.0f);
+    p = rt_fma<EXACT>(p, x2, 1.0f);
+    const float sx = x * p;
+
+    float q = 1.0f / 40320.0f;
+    q = rt_fma<EXACT>(q, x2, -1.0f / 720.0f);
+    q = rt_fma<EXACT>(q, x2, 1.0f / 24.0f);
+    q = rt_fma<EXACT>(q, x2, -0.5f);
+    q = rt_fma<EXACT>(q, x2, 1.0f);
+    const float cx = q;
+
+    const bool swap = ((oct + 1) >> 1) & 1;
+    float c = swap ? sx : cx;
+    float s = swap ? cx : sx;
+    if(oct >= 2 && oct <= 5) c = -c;
+    if(oct >= 4) s = -s;
+    c_out = c;
+    s_out = s;
+}
+
+template <bool EXACT>
+__device__ __forceinline__ f3 unit_vector(uint32_t bits) {
+    const float u1 = static_cast<float>(bits >> 16) * (1.0f / 65536.0f);
+    const float u2 = static_cast<float>(bits & 0xffffu) * (1.0f / 65536.0f);
+    const float z = 1.0f - 2.0f * u1;
+    const float m = 1.0f - z * z;
+    const float r = rt_sqrt<EXACT>(m > 0.0f ? m : 0.0f);
+    float c, s;
+    cossin_2pi<EXACT>(u2, c, s);
+    return f3{r * c, r * s, z};
+}
+
+// ------------------------------------------------------------------------------------------
+// primary pass: the reference's pixel kernel, 4 horizontally adjacent pixels per lane so the
+// packed image leaves as one 16-byte store per lane (1 KiB per wave instruction)
+// ------------------------------------------------------------------------------------------
+
+template <bool EXACT>
+__device__ __forceinline__ uint32_t primary_pixel(const view_consts &vc, const float4 sphere, uint32_t x, uint32_t y,
+                                                  const f3 bg, f3 &rgb_out) {
+    const f3 cam = {vc.cam[0], vc.cam[1], vc.cam[2]};
+    const f3 d = primary_direction<EXACT>(vc, static_cast<float>(x) + 0.5f, static_cast<float>(y) + 0.5f);
+
+    // src/shapes.cpp:14-20 ; sphere.w holds radius*radius
+    const f3 oc = {sphere.x - cam.x, sphere.y - cam.y, sphere.z - cam.z};
+    const float a = dot3<EXACT>(d, d);
+    const float b = -2.0f * dot3<EXACT>(d, oc);
+    const float c = dot3<EXACT>(oc, oc) - sphere.w;
+    const float disc = rt_fma<EXACT>(-(4.0f * a), c, b * b);    // b*b - (4a)*c
+
+    f3 rgb = bg;
+    if(disc >= 0.0f) {
+        // src/shapes.cpp:23-25 : nearest root, no range test
+        const float t = rt_div<EXACT>(-b - rt_sqrt<EXACT>(disc), 2.0f * a);
+        const f3 p = {rt_fma<EXACT>(d.x, t, cam.x), rt_fma<EXACT>(d.y, t, cam.y), rt_fma<EXACT>(d.z, t, cam.z)};
+        const f3 n = normalize3<EXACT>(f3{p.x - sphere.x, p.y - sphere.y, p.z - sphere.z});
+        rgb = f3{remap_unit(n.x), remap_unit(n.y), remap_unit(n.z)};
+    }
+    rgb_out = rgb;
+    return pack_argb32(rgb.x, rgb.y, rgb.z);
+}
+
+// Exact build note: "b*b - (4a)*c" above goes through rt_fma<true>(-(4a), c, b*b) =
+// (-(4a))*c + b*b, which rounds the product first and then the sum: the same two roundings as
+// b*b - (4a)*c, because negation is exact and x + (-y) == x - y in IEEE arithmetic.
+
+template <bool EXACT, bool VEC4>
+__global__ __launch_bounds__(kPrimaryBlock) void primary_kernel(view_consts vc, float4 sphere,
+                                                                 uint32_t *__restrict__ argb,
+                                                                 float4 *__restrict__ rgba) {
+    constexpr uint32_t PX = VEC4 ? 4u : 1u;
+    const uint32_t groups_per_row = vc.width / PX;
+    const uint32_t gid = blockIdx.x * kPrimaryBlock + threadIdx.x;
+    if(gid >= groups_per_row * vc.row_count) return;
+
+    const uint32_t row = gid / groups_per_row;
+    const uint32_t x0 = (gid - row * groups_per_row) * PX;
+    const uint32_t y = vc.row_begin + row;
+    const f3 bg = row_background<EXACT>(vc, y);
+
+    uint32_t packed[PX];
+    f3 rgb[PX];
+#pragma unroll
+    for(uint32_t i = 0; i < PX; i++) packed[i] = primary_pixel<EXACT>(vc, sphere, x0 + i, y, bg, rgb[i]);
+
+    const size_t base = static_cast<size_t>(row) * vc.width + x0;
+    if constexpr(VEC4) {
+        *reinterpret_cast<uint4 *>(argb + base) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+    } else {
+        argb[base] = packed[0];
+    }
+    if(rgba) {
+#pragma unroll
+        for(uint32_t i = 0; i < PX; i++) rgba[base + i] = make_float4(rgb[i].x, rgb[i].y, rgb[i].z, 1.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// path pass
+// ------------------------------------------------------------------------------------------
+
+struct path_state {
+    f3 o, d, thr;
+    uint32_t rng;
+    uint32_t bounce;
+};
+
+template <bool EXACT>
+__device__ __forceinline__ void start_path(const view_consts &vc, uint32_t x, uint32_t y, uint32_t sample, path_state &ps) {
+    const uint32_t key = path_key(vc.seed_hash, y * vc.width + x, sample);
+    float jx = 0.5f, jy = 0.5f;
+    if(vc.flags & AEHIP_FLAG_JITTER) {
+        jx = static_cast<float>(key >> 16) * (1.0f / 65536.0f);
+        jy = static_cast<float>(key & 0xffffu) * (1.0f / 65536.0f);
+    }
+    ps.rng = key;
+    ps.bounce = 0;
+    ps.o = f3{vc.cam[0], vc.cam[1], vc.cam[2]};
+    ps.d = primary_direction<EXACT>(vc, static_cast<float>(x) + jx, static_cast<float>(y) + jy);
+    ps.thr = f3{1.0f, 1.0f, 1.0f};
+}
+
+// Tests the ray against spheres [0,count) of an LDS chunk (sphere = centre xyz, w = r*r).
+// Quadratic as src/shapes.cpp:14-23 with a (t_min, closest) range test and the far root added.
+template <bool EXACT>
+__device__ __forceinline__ void intersect_chunk(const float4 *__restrict__ s_geom, uint32_t count, uint32_t index_base,
+                                                const f3 o, const f3 d, float a2, float a4, float &closest, int &hit) {
+#pragma unroll 4
+    for(uint32_t i = 0; i < count; i++) {
+        const float4 g = s_geom[i];
+        const f3 oc = {g.x - o.x, g.y - o.y, g.z - o.z};
+        const float b = -2.0f * dot3<EXACT>(d, oc);
+        const float c = dot3<EXACT>(oc, oc) - g.w;
+        const float disc = rt_fma<EXACT>(-a4, c, b * b);
+        if(disc >= 0.0f) {
+            const float sq = rt_sqrt<EXACT>(disc);
+            float t = rt_div<EXACT>(-b - sq, a2);
+            bool ok = (t > kTMin) && (t < closest);
+            if(!ok) {
+                t = rt_div<EXACT>(-b + sq, a2);
+                ok = (t > kTMin) && (t < closest);
+            }
+            if(ok) {
+                closest = t;
+                hit = static_cast<int>(index_base + i);
+            }
+        }
+    }
+}
+
+// Shades the hit (or miss) of the current segment.  Returns true when the path ended with
+// radiance L; false when it continues with ps updated.
+template <bool EXACT>
+__device__ __forceinline__ bool shade_segment(const view_consts &vc, uint32_t y, int hit, float closest,
+                                              const float4 *__restrict__ geom, const float4 *__restrict__ matl,
+                                              const uint32_t *__restrict__ kind, path_state &ps, f3 &L) {
+    L = f3{0.0f, 0.0f, 0.0f};
+    if(hit < 0) {
+        f3 sky;
+        if(ps.bounce == 0) {
+            sky = row_background<EXACT>(vc, y);
+        } else {
+            const float t = 0.5f * (ps.d.y + 1.0f);
+            sky = f3{lerp1<EXACT>(t, vc.bg0[0], vc.bg1[0]), lerp1<EXACT>(t, vc.bg0[1], vc.bg1[1]),
+                     lerp1<EXACT>(t, vc.bg0[2], vc.bg1[2])};
+        }
+        L = f3{ps.thr.x * sky.x, ps.thr.y * sky.y, ps.thr.z * sky.z};
+        return true;
+    }
+
+    const float4 g = geom[hit];
+    const uint32_t material = kind[hit];
+    const f3 pt = {rt_fma<EXACT>(ps.d.x, closest, ps.o.x), rt_fma<EXACT>(ps.d.y, closest, ps.o.y),
+                   rt_fma<EXACT>(ps.d.z, closest, ps.o.z)};
+    const f3 n_out = normalize3<EXACT>(f3{pt.x - g.x, pt.y - g.y, pt.z - g.z});
+
+    if(material == AEHIP_MAT_NORMAL) {
+        L = f3{ps.thr.x * remap_unit(n_out.x), ps.thr.y * remap_unit(n_out.y), ps.thr.z * remap_unit(n_out.z)};
+        return true;
+    }
+
+    const float4 m = matl[hit];
+    const float dn = dot3<EXACT>(ps.d, n_out);
+    const bool front = dn < 0.0f;
+    const f3 n = front ? n_out : f3{-n_out.x, -n_out.y, -n_out.z};
+    f3 nd;
+
+    if(material == AEHIP_MAT_LAMBERT) {
+        const f3 u = unit_vector<EXACT>(rng_next(ps.rng));
+        nd = f3{n.x + u.x, n.y + u.y, n.z + u.z};
+        if(__builtin_fabsf(nd.x) < 1e-8f && __builtin_fabsf(nd.y) < 1e-8f && __builtin_fabsf(nd.z) < 1e-8f) nd = n;
+    } else if(material == AEHIP_MAT_METAL) {
+        const float k = 2.0f * dot3<EXACT>(ps.d, n);
+        nd = f3{rt_fma<EXACT>(-k, n.x, ps.d.x), rt_fma<EXACT>(-k, n.y, ps.d.y), rt_fma<EXACT>(-k, n.z, ps.d.z)};
+        if(m.w > 0.0f) {
+            const f3 u = unit_vector<EXACT>(rng_next(ps.rng));
+            nd = f3{rt_fma<EXACT>(m.w, u.x, nd.x), rt_fma<EXACT>(m.w, u.y, nd.y), rt_fma<EXACT>(m.w, u.z, nd.z)};
+        }
+        if(!(dot3<EXACT>(nd, n) > 0.0f)) return true;      // absorbed
+    } else {
+        const float ri = front ? rt_div<EXACT>(1.0f, m.w) : m.w;
+        const f3 md = {-ps.d.x, -ps.d.y, -ps.d.z};
+        const float cd = dot3<EXACT>(md, n);
+        const float cos_t = cd < 1.0f ? cd : 1.0f;
+        const float s2 = 1.0f - cos_t * cos_t;
+        const float sin_t = rt_sqrt<EXACT>(s2 > 0.0f ? s2 : 0.0f);
+        float r0 = rt_div<EXACT>(1.0f - ri, 1.0f + ri);
+        r0 = r0 * r0;
+        const float w = 1.0f - cos_t;
+        const float w2 = w * w;
+        const float reflectance = rt_fma<EXACT>(1.0f - r0, (w2 * w2) * w, r0);
+        const float u = static_cast<float>(rng_next(ps.rng) >> 8) * (1.0f / 16777216.0f);
+        if(ri * sin_t > 1.0f || reflectance > u) {
+            const float k = 2.0f * dot3<EXACT>(ps.d, n);
+            nd = f3{rt_fma<EXACT>(-k, n.x, ps.d.x), rt_fma<EXACT>(-k, n.y, ps.d.y), rt_fma<EXACT>(-k, n.z, ps.d.z)};
+        } else {
+            const f3 perp = {(rt_fma<EXACT>(n.x, cos_t, ps.d.x)) * ri, (rt_fma<EXACT>(n.y, cos_t, ps.d.y)) * ri,
+                             (rt_fma<EXACT>(n.z, cos_t, ps.d.z)) * ri};
+            const float par = -rt_sqrt<EXACT>(__builtin_fabsf(1.0f - dot3<EXACT>(perp, perp)));
+            nd = f3{rt_fma<EXACT>(n.x, par, perp.x), rt_fma<EXACT>(n.y, par, perp.y), rt_fma<EXACT>(n.z, par, perp.z)};
+        }
+    }
+
+    ps.thr = f3{ps.thr.x * m.x, ps.thr.y * m.y, ps.thr.z * m.z};
+    ps.o = pt;
+    ps.d = normalize3<EXACT>(nd);
+    ps.bounce += 1;
+    if(ps.bounce >= vc.max_depth) return true;              // depth exhausted: no light
+    return false;
+}
+
+// One lane owns one pixel and walks its samples in index order; the moment a path ends the lane
+// starts the pixel's next sample (path regeneration), so a wave only idles lanes whose pixel is
+// complete.  The sum over samples is therefore sequential per pixel whatever the divergence.
+//
+// SINGLE_CHUNK: the whole shape list fits the LDS buffer and is staged once; no barrier inside
+// the segment loop, each wave leaves when its own lanes are done.  Otherwise the list streams
+// through LDS in chunks and the workgroup iterates segments together.
+template <bool EXACT, bool SINGLE_CHUNK>
+__global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const float4 *__restrict__ geom,
+                                                      const float4 *__restrict__ matl,
+                                                      const uint32_t *__restrict__ kind, uint32_t *__restrict__ argb,
+                                                      float4 *__restrict__ rgba, unsigned long long *ray_counter) {
+    __shared__ float4 s_geom[kLdsSpheres];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t x = blockIdx.x * kTileW + (tid & (kTileW - 1));
+    const uint32_t row = blockIdx.y * kTileH + (tid / kTileW);
+    const uint32_t y = vc.row_begin + row;
+    const bool valid = (x < vc.width) && (row < vc.row_count);
+
+    if constexpr(SINGLE_CHUNK) {
+        for(uint32_t i = tid; i < vc.n_spheres; i += kBlock) s_geom[i] = geom[i];
+        __syncthreads();
+    }
+
+    f3 sum = {0.0f, 0.0f, 0.0f};
+    uint32_t sample = 0;
+    uint32_t nrays = 0;
+    bool alive = valid;
+    path_state ps;
+    ps.o = ps.d = ps.thr = f3{0.0f, 0.0f, 0.0f};
+    ps.rng = 0;
+    ps.bounce = 0;
+    if(alive) start_path<EXACT>(vc, x, y, 0, ps);
+
+    for(;;) {
+        if constexpr(SINGLE_CHUNK) {
+            if(!__any(alive)) break;
+        } else {
+            if(!__syncthreads_or(alive)) break;
+        }
+
+        const float a = dot3<EXACT>(ps.d, ps.d);
+        const float a4 = 4.0f * a;
+        const float a2 = 2.0f * a;
+        float closest = 3.402823466e+38f;
+        int hit = -1;
+
+        if constexpr(SINGLE_CHUNK) {
+            if(alive) intersect_chunk<EXACT>(s_geom, vc.n_spheres, 0, ps.o, ps.d, a2, a4, closest, hit);
+        } else {
+            for(uint32_t base = 0; base < vc.n_spheres; base += kLdsSpheres) {
+                const uint32_t count = min(static_cast<uint32_t>(kLdsSpheres), vc.n_spheres - base);
+                __syncthreads();
+                for(uint32_t i = tid; i < count; i += kBlock) s_geom[i] = geom[base + i];
+                __syncthreads();
+                if(alive) intersect_chunk<EXACT>(s_geom, count, base, ps.o, ps.d, a2, a4, closest, hit);
+            }
+        }
+
+        if(alive) {
+            nrays++;
+            f3 L;
+            if(shade_segment<EXACT>(vc, y, hit, closest, geom, matl, kind, ps, L)) {
+                sum.x += L.x;
+                sum.y += L.y;
+                sum.z += L.z;
+                sample++;
+                if(sample < vc.spp) start_path<EXACT>(vc, x, y, sample, ps);
+                else alive = false;
+            }
+        }
+    }
+
+    if(valid) {
+        const float n = static_cast<float>(vc.spp);
+        const float r = clamp01(rt_div<EXACT>(sum.x, n));
+        const float g = clamp01(rt_div<EXACT>(sum.y, n));
+        const float b = clamp01(rt_div<EXACT>(sum.z, n));
+        const size_t idx = static_cast<size_t>(row) * vc.width + x;
+        argb[idx] = pack_argb32(r, g, b);
+        if(rgba) rgba[idx] = make_float4(r, g, b, 1.0f);
+    }
+
+    if(vc.flags & AEHIP_FLAG_COUNT_RAYS) {
+        // wave-level sum, one atomic per wave
+        uint32_t v = nrays;
+#pragma unroll
+        for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if((tid & 63u) == 0) atomicAdd(ray_counter, static_cast<unsigned long long>(v));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: error reporting, backend object, C ABI
+// ------------------------------------------------------------------------------------------
+
+thread_local char g_error[512] = "";
+bool g_initialised = false;
+int g_device_count = 0;
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define AEHIP_CHECK(expr)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if(e_ != hipSuccess) return fail(AEHIP_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));  \
+    } while(0)
+
+}  // namespace
+
+struct aehip_backend {
+    int device = 0;
+    uint32_t *framebuffer = nullptr;        // borrowed
+    bool ready = false;
+
+    aehip_params params{};
+    view_consts vc{};
+    float4 sphere0{};                        // primary pass: centre xyz, w = r*r
+
+    float4 *d_geom = nullptr;                // n x (cx, cy, cz, r*r)
+    float4 *d_matl = nullptr;                // n x (albedo rgb, param)
+    uint32_t *d_kind = nullptr;              // n x material id
+    uint32_t scene_capacity = 0;
+
+    uint32_t *d_argb = nullptr;              // own output band (aehip_backend_trace)
+    size_t argb_capacity = 0;                // pixels
+    uint32_t *h_staging = nullptr;           // pinned
+    size_t staging_capacity = 0;
+    unsigned long long *d_rays = nullptr;
+
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_copy = nullptr;
+    bool timed_on_own_stream = false;
+    aehip_stats stats{};
+};
+
+namespace {
+
+int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t stream) {
+    const view_consts &vc = b->vc;
+    const bool exact = !(vc.flags & AEHIP_FLAG_FAST);
+    float4 *rgba = reinterpret_cast<float4 *>(rgba_dev);
+    const void *func = nullptr;
+
+    if(vc.flags & AEHIP_FLAG_COUNT_RAYS) AEHIP_CHECK(hipMemsetAsync(b->d_rays, 0, sizeof(unsigned long long), stream));
+
+    if(b->params.pass == AEHIP_PASS_PRIMARY) {
+        const bool vec4 = (vc.width % 4u) == 0 && (reinterpret_cast<uintptr_t>(argb_dev) % 16u) == 0;
+        const uint64_t groups = static_cast<uint64_t>(vc.width / (vec4 ? 4u : 1u)) * vc.row_count;
+        const dim3 grid(static_cast<uint32_t>((groups + kPrimaryBlock - 1) / kPrimaryBlock));
+        if(exact && vec4) { func = reinterpret_cast<const void *>(primary_kernel<true, true>); hipLaunchKernelGGL((primary_kernel<true, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->sphere0, argb_dev, rgba); }
+        else if(exact) { func = reinterpret_cast<const void *>(primary_kernel<true, false>); hipLaunchKernelGGL((primary_kernel<true, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->sphere0, argb_dev, rgba); }
+        else if(vec4) { func = reinterpret_cast<const void *>(primary_kernel<false, true>); hipLaunchKernelGGL((primary_kernel<false, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->sphere0, argb_dev, rgba); }
+        else { func = reinterpret_cast<const void *>(primary_kernel<false, false>); hipLaunchKernelGGL((primary_kernel<false, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->sphere0, argb_dev, rgba); }
+    } else {
+        const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + kTileH - 1) / kTileH);
+        const bool single = vc.n_spheres <= static_cast<uint32_t>(kLdsSpheres);
+        if(exact && single) { func = reinterpret_cast<const void *>(path_kernel<true, true>); hipLaunchKernelGGL((path_kernel<true, true>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind, argb_dev, rgba, b->d_rays); }
+        else if(exact) { func = reinterpret_cast<const void *>(path_kernel<true, false>); hipLaunchKernelGGL((path_kernel<true, false>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind, argb_dev, rgba, b->d_rays); }
+        else if(single) { func = reinterpret_cast<const void *>(path_kernel<false, true>); hipLaunchKernelGGL((path_kernel<false, true>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind, argb_dev, rgba, b->d_rays); }
+        else { func = reinterpret_cast<const void *>(path_kernel<false, false>); hipLaunchKernelGGL((path_kernel<false, false>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind, argb_dev, rgba, b->d_rays); }
+    }
+    AEHIP_CHECK(hipGetLastError());
+
+    hipFuncAttributes attr;
+    if(hipFuncGetAttributes(&attr, func) == hipSuccess) {
+        b->stats.vgprs = static_cast<uint32_t>(attr.numRegs);
+        b->stats.lds_bytes = static_cast<uint32_t>(attr.sharedSizeBytes);
+    }
+    b->stats.paths = static_cast<uint64_t>(vc.width) * vc.row_count * (b->params.pass == AEHIP_PASS_PRIMARY ? 1u : vc.spp);
+    return AEHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int aehip_init(void) {
+    if(g_initialised) return g_device_count > 0 ? AEHIP_OK : AEHIP_E_NO_DEVICE;
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if(e != hipSuccess || n <= 0) {
+        g_device_count = 0;
+        return fail(AEHIP_E_NO_DEVICE, "no HIP device: %s", e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    }
+    g_device_count = n;
+    g_initialised = true;
+    return AEHIP_OK;
+}
+
+void aehip_terminate(void) {
+    g_initialised = false;
+    g_device_count = 0;
+}
+
+int aehip_device_count(void) { return g_initialised ? g_device_count : 0; }
+
+const char *aehip_last_error(void) { return g_error; }
+
+int aehip_backend_create(int device, uint32_t *framebuffer, aehip_backend **out) {
+    if(!out) return fail(AEHIP_E_INVALID, "aehip_backend_create: out is null");
+    *out = nullptr;
+    if(!g_initialised) {
+        const int rc = aehip_init();
+        if(rc != AEHIP_OK) return rc;
+    }
+    if(device < 0 || device >= g_device_count) return fail(AEHIP_E_INVALID, "device %d out of range (0..%d)", device, g_device_count - 1);
+
+    aehip_backend *b = new(std::nothrow) aehip_backend();
+    if(!b) return fail(AEHIP_E_INVALID, "out of host memory");
+    b->device = device;
+    b->framebuffer = framebuffer;
+
+    hipError_t e = hipSetDevice(device);
+    if(e == hipSuccess) e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if(e == hipSuccess) e = hipEventCreate(&b->ev_begin);
+    if(e == hipSuccess) e = hipEventCreate(&b->ev_end);
+    if(e == hipSuccess) e = hipEventCreate(&b->ev_copy);
+    if(e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_rays), sizeof(unsigned long long));
+    if(e != hipSuccess) {
+        const int rc = fail(AEHIP_E_HIP, "backend create on device %d: %s", device, hipGetErrorString(e));
+        aehip_backend_destroy(b);
+        return rc;
+    }
+    *out = b;
+    return AEHIP_OK;
+}
+
+void aehip_backend_destroy(aehip_backend *b) {
+    if(!b) return;
+    (void)hipSetDevice(b->device);
+    if(b->stream) (void)hipStreamSynchronize(b->stream);
+    if(b->d_geom) (void)hipFree(b->d_geom);
+    if(b->d_matl) (void)hipFree(b->d_matl);
+    if(b->d_kind) (void)hipFree(b->d_kind);
+    if(b->d_argb) (void)hipFree(b->d_argb);
+    if(b->d_rays) (void)hipFree(b->d_rays);
+    if(b->h_staging) (void)hipHostFree(b->h_staging);
+    if(b->ev_begin) (void)hipEventDestroy(b->ev_begin);
+    if(b->ev_end) (void)hipEventDestroy(b->ev_end);
+    if(b->ev_copy) (void)hipEventDestroy(b->ev_copy);
+    if(b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_params *params) {
+    if(!b || !scene || !params) return fail(AEHIP_E_INVALID, "aehip_backend_setup: null argument");
+    b->ready = false;
+    aehip_params p = *params;
+    if(p.width == 0 || p.height == 0) return fail(AEHIP_E_INVALID, "resolution %ux%u is empty", p.width, p.height);
+    if(p.width > 65535u || p.height > 65535u) return fail(AEHIP_E_TOO_LARGE, "resolution %ux%u exceeds 65535 per side", p.width, p.height);
+    if(p.row_count == 0) {
+        if(p.row_begin >= p.height) return fail(AEHIP_E_INVALID, "row_begin %u outside image of %u rows", p.row_begin, p.height);
+        p.row_count = p.height - p.row_begin;
+    }
+    if(p.row_begin + static_cast<uint64_t>(p.row_count) > p.height) return fail(AEHIP_E_INVALID, "rows [%u,%u) outside image of %u rows", p.row_begin, p.row_begin + p.row_count, p.height);
+    if(p.pass != AEHIP_PASS_PRIMARY && p.pass != AEHIP_PASS_PATH) return fail(AEHIP_E_INVALID, "unknown pass %u", p.pass);
+    if(p.spp == 0 || p.max_depth == 0) return fail(AEHIP_E_INVALID, "spp and max_depth must be >= 1");
+    if(scene->sphere_count == 0 || !scene->spheres) return fail(AEHIP_E_INVALID, "scene has no spheres");
+    for(uint32_t i = 0; i < scene->sphere_count; i++) {
+        if(scene->spheres[i].material > AEHIP_MAT_DIELECTRIC) return fail(AEHIP_E_INVALID, "sphere %u: unknown material %u", i, scene->spheres[i].material);
+    }
+
+    AEHIP_CHECK(hipSetDevice(b->device));
+
+    // viewport: src/software_raytracer.cpp:68-91
+    float vw, vh;
+    if(p.width > p.height) {
+        vw = static_cast<float>(p.width) / static_cast<float>(p.height);
+        vh = 1.0f;
+    } else {
+        vw = 1.0f;
+        vh = static_cast<float>(p.height) / static_cast<float>(p.width);
+    }
+    view_consts &vc = b->vc;
+    vc.vw_half = vw * 0.5f;
+    vc.vh_half = vh * 0.5f;
+    vc.psx = vw / static_cast<float>(p.width);
+    vc.psy = vh / static_cast<float>(p.height);
+    for(int i = 0; i < 3; i++) {
+        vc.cam[i] = scene->camera_pos[i];
+        vc.bg0[i] = scene->background0[i];
+        vc.bg1[i] = scene->background1[i];
+    }
+    vc.width = p.width;
+    vc.height = p.height;
+    vc.row_begin = p.row_begin;
+    vc.row_count = p.row_count;
+    vc.spp = p.spp;
+    vc.max_depth = p.max_depth;
+    vc.seed_hash = pcg_hash(p.seed);
+    vc.flags = p.flags;
+    vc.n_spheres = scene->sphere_count;
+
+    // scene upload (replicated on every GPU that renders a band)
+    const uint32_t n = scene->sphere_count;
+    if(n > b->scene_capacity) {
+        if(b->d_geom) (void)hipFree(b->d_geom);
+        if(b->d_matl) (void)hipFree(b->d_matl);
+        if(b->d_kind) (void)hipFree(b->d_kind);
+        b->d_geom = nullptr; b->d_matl = nullptr; b->d_kind = nullptr; b->scene_capacity = 0;
+        AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_geom), sizeof(float4) * n));
+        AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_matl), sizeof(float4) * n));
+        AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_kind), sizeof(uint32_t) * n));
+        b->scene_capacity = n;
+    }
+    {
+        float4 *geom = static_cast<float4 *>(std::malloc(sizeof(float4) * n));
+        float4 *matl = static_cast<float4 *>(std::malloc(sizeof(float4) * n));
+        uint32_t *kind = static_cast<uint32_t *>(std::malloc(sizeof(uint32_t) * n));
+        if(!geom || !matl || !kind) {
+            std::free(geom); std::free(matl); std::free(kind);
+            return fail(AEHIP_E_INVALID, "out of host memory staging %u spheres", n);
+        }
+        for(uint32_t i = 0; i < n; i++) {
+            const aehip_sphere &s = scene->spheres[i];
+            const float r = std::fabs(s.radius);                      // src/shapes.cpp:10-12
+            geom[i] = make_float4(s.center[0], s.center[1], s.center[2], r * r);
+            matl[i] = make_float4(s.albedo[0], s.albedo[1], s.albedo[2], s.param);
+            kind[i] = s.material;
+        }
+        b->sphere0 = geom[0];
+        hipError_t e = hipMemcpyAsync(b->d_geom, geom, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
+        if(e == hipSuccess) e = hipMemcpyAsync(b->d_matl, matl, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
+        if(e == hipSuccess) e = hipMemcpyAsync(b->d_kind, kind, sizeof(uint32_t) * n, hipMemcpyHostToDevice, b->stream);
+        if(e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        std::free(geom); std::free(matl); std::free(kind);
+        if(e != hipSuccess) return fail(AEHIP_E_HIP, "scene upload: %s", hipGetErrorString(e));
+    }
+
+    b->params = p;
+    b->ready = true;
+    return AEHIP_OK;
+}
+
+int aehip_backend_trace_device(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, void *hip_stream) {
+    if(!b) return fail(AEHIP_E_INVALID, "aehip_backend_trace_device: backend is null");
+    if(!b->ready) return fail(AEHIP_E_NOT_SETUP, "trace before a successful setup");
+    if(!argb_dev) return fail(AEHIP_E_INVALID, "argb_dev is null");
+    AEHIP_CHECK(hipSetDevice(b->device));
+    const bool own = hip_stream == nullptr;
+    hipStream_t stream = own ? b->stream : static_cast<hipStream_t>(hip_stream);
+    AEHIP_CHECK(hipEventRecord(b->ev_begin, stream));
+    const int rc = launch(b, argb_dev, rgba_dev, stream);
+    if(rc != AEHIP_OK) return rc;
+    AEHIP_CHECK(hipEventRecord(b->ev_end, stream));
+    b->timed_on_own_stream = own;
+    if(own) AEHIP_CHECK(hipStreamSynchronize(stream));
+    return AEHIP_OK;
+}
+
+int aehip_backend_trace(aehip_backend *b) {
+    if(!b) return fail(AEHIP_E_INVALID, "aehip_backend_trace: backend is null");
+    if(!b->ready) return fail(AEHIP_E_NOT_SETUP, "trace before a successful setup");
+    if(!b->framebuffer) return fail(AEHIP_E_INVALID, "backend was created without a framebuffer");
+    AEHIP_CHECK(hipSetDevice(b->device));
+
+    const size_t pixels = static_cast<size_t>(b->vc.width) * b->vc.row_count;
+    if(pixels > b->argb_capacity) {
+        if(b->d_argb) (void)hipFree(b->d_argb);
+        b->d_argb = nullptr; b->argb_capacity = 0;
+        AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_argb), pixels * sizeof(uint32_t)));
+        b->argb_capacity = pixels;
+    }
+    if(pixels > b->staging_capacity) {
+        if(b->h_staging) (void)hipHostFree(b->h_staging);
+        b->h_staging = nullptr; b->staging_capacity = 0;
+        AEHIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&b->h_staging), pixels * sizeof(uint32_t), hipHostMallocDefault));
+        b->staging_capacity = pixels;
+    }
+
+    AEHIP_CHECK(hipEventRecord(b->ev_begin, b->stream));
+    const int rc = launch(b, b->d_argb, nullptr, b->stream);
+    if(rc != AEHIP_OK) return rc;
+    AEHIP_CHECK(hipEventRecord(b->ev_end, b->stream));
+    // The borrowed framebuffer is usually a MAP_SHARED file mapping (src/output_linux.cpp:24-29):
+    // copy device -> pinned staging at full PCIe rate, then one memcpy into the mapping.
+    AEHIP_CHECK(hipMemcpyAsync(b->h_staging, b->d_argb, pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    AEHIP_CHECK(hipEventRecord(b->ev_copy, b->stream));
+    AEHIP_CHECK(hipStreamSynchronize(b->stream));
+    std::memcpy(b->framebuffer, b->h_staging, pixels * sizeof(uint32_t));
+    b->timed_on_own_stream = true;
+    float ms = 0.0f;
+    if(hipEventElapsedTime(&ms, b->ev_end, b->ev_copy) == hipSuccess) b->stats.copy_ms = ms;
+    return AEHIP_OK;
+}
+
+int aehip_backend_stats(aehip_backend *b, aehip_stats *out) {
+    if(!b || !out) return fail(AEHIP_E_INVALID, "aehip_backend_stats: null argument");
+    AEHIP_CHECK(hipSetDevice(b->device));
+    AEHIP_CHECK(hipEventSynchronize(b->ev_end));
+    float ms = 0.0f;
+    AEHIP_CHECK(hipEventElapsedTime(&ms, b->ev_begin, b->ev_end));
+    b->stats.kernel_ms = ms;
+    if(b->vc.flags & AEHIP_FLAG_COUNT_RAYS) {
+        unsigned long long rays = 0;
+        AEHIP_CHECK(hipMemcpy(&rays, b->d_rays, sizeof(rays), hipMemcpyDeviceToHost));
+        b->stats.rays = rays;
+    } else {
+        b->stats.rays = 0;
+    }
+    *out = b->stats;
+    return AEHIP_OK;
+}
+
+}  // extern "C"
