@@ -62,7 +62,7 @@ def cpu_baseline(target_seconds: float):
     _, _, _, ms = oracle.trace_paths(WIDTH, HEIGHT, spp=1, max_depth=8, seed=1, jitter=True, row_begin=1000,
                                      row_count=64, threads=threads)
     per_spp_s = ms * 1e-3 * HEIGHT / 64.0
-    spp = max(1, min(64, int(target_seconds / max(per_spp_s, 1e-6))))
+    spp = max(1, min(1024, int(target_seconds / max(per_spp_s, 1e-6))))
     _, _, rays, ms = oracle.trace_paths(WIDTH, HEIGHT, spp=spp, max_depth=8, seed=1, jitter=True, threads=threads)
     out = {
         "value": WIDTH * HEIGHT * spp / (ms * 1e-3) / 1e6,

@@ -98,6 +98,15 @@ def load() -> ctypes.CDLL:
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise HipRaytracerError(f"{LIB_PATH} is missing: build it with `make lib` (hipcc, gfx950)")
+        # A process must hold ONE HIP runtime.  PyTorch wheels bundle their own libamdhip64.so.7;
+        # if this library pulled in /opt/rocm's copy first, torch would later fail with "No HIP
+        # GPUs are available".  Python drivers use torch for device memory and collectives, so
+        # let torch load its runtime first; this library then binds to the same one by soname.
+        if os.environ.get("RAYTRACER_AMD_NO_TORCH") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = ctypes.CDLL(LIB_PATH)
         vp = ctypes.c_void_p
         L.aehip_init.restype = ctypes.c_int
