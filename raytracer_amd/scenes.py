@@ -92,3 +92,23 @@ SCENES = {
     "divergence": divergence_scene,
     "showcase": showcase_scene,
 }
+
+
+_MATERIAL_NAMES = {MAT_NORMAL: "normal", MAT_LAMBERT: "lambert", MAT_METAL: "metal", MAT_DIELECTRIC: "dielectric"}
+
+
+def save_scene(path: str, spheres: np.ndarray, camera=None, background0=None, background1=None) -> None:
+    """Writes the text scene format the host CLI reads with --scene.  Floats are printed with 9
+    significant digits, which round-trips binary32 exactly."""
+    f9 = lambda v: " ".join(f"{float(x):.9g}" for x in v)
+    with open(path, "w") as f:
+        f.write("# raytracer_hip scene\n")
+        if camera is not None:
+            f.write(f"camera {f9(camera)}\n")
+        if background0 is not None:
+            f.write(f"background0 {f9(background0)}\n")
+        if background1 is not None:
+            f.write(f"background1 {f9(background1)}\n")
+        for s in spheres:
+            f.write(f"sphere {f9(s['center'])} {float(s['radius']):.9g} {_MATERIAL_NAMES[int(s['material'])]} "
+                    f"{f9(s['albedo'])} {float(s['param']):.9g}\n")

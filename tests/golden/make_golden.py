@@ -80,6 +80,35 @@ def main():
         meta["scheduler_runs"].append({"width": w, "height": h, "sha256": digests.pop(),
                                        "tga_header_hex": header.hex(), "file_size": size})
 
+    # Command-line behaviour of the reference program itself: (arguments) -> size in the TGA
+    # header it writes and the length of the file.
+    cli_cases = [
+        [],
+        ["--width", "1001", "--height", "3"],
+        ["--width", "abc", "--height", "64"],
+        ["--width", "0", "--height", "8"],
+        ["--width", "64", "--width", "128", "--height", "32"],
+        ["--width", "12x", "--width", "128", "--height", "32"],
+        ["--height", "100", "--width"],
+        ["--bogus", "--width", "256", "stray", "--height", "16"],
+        ["--width", "+20", "--height", " 24"],
+        ["--width", "18446744073709551615", "--height", "40"],
+        ["--width", "-4294967200", "--height", "12"],
+        ["--width", "70", "--height", "6", "--compute"],
+    ]
+    cli = []
+    for args in cli_cases:
+        with tempfile.TemporaryDirectory() as td:
+            subprocess.run([REFBIN, *args], check=True, cwd=td)
+            with open(os.path.join(td, "output.tga"), "rb") as f:
+                header = f.read(18)
+            size = os.path.getsize(os.path.join(td, "output.tga"))
+        cli.append({"args": args, "width": int.from_bytes(header[12:14], "little"),
+                    "height": int.from_bytes(header[14:16], "little"), "header_hex": header.hex(), "file_size": size})
+        print("cli", args, cli[-1]["width"], cli[-1]["height"], size)
+    with open(os.path.join(HERE, "reference_cli.json"), "w") as f:
+        json.dump({"generator": "tests/golden/make_golden.py", "cases": cli}, f, indent=1)
+
     rng = np.random.default_rng(20241220)
     for (w, h) in FLOAT_PROBE_SIZES:
         xs = rng.integers(0, w, PROBES_PER_SIZE - 8)

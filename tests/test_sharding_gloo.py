@@ -1,0 +1,61 @@
+"""The N>1 path of bench.py on CPU: row-band partition + gather to rank 0 over torch.distributed
+(gloo here, RCCL on the GPU box).  Bands are filled by the CPU oracle, which stands in for the
+per-rank render; what is under test is the sharding and the collective."""
+import hashlib
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from raytracer_amd.sharding import BandGather, band_bounds, band_of
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+META = json.load(open(os.path.join(GOLDEN, "reference_images.json")))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_band_bounds_cover_the_image_without_overlap():
+    for height in (4, 8, 270, 1080, 2160, 2161):
+        for world in (1, 2, 3, 4, 7, 8):
+            b = band_bounds(height, world)
+            assert b[0] == 0 and b[-1] == height and all(b[i] <= b[i + 1] for i in range(world))
+            sizes = [b[i + 1] - b[i] for i in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+            assert band_of(height, world, world - 1) == (b[-2], sizes[-1])
+
+
+def _worker(rank, world, port, width, height, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = BandGather(width, height, torch.device("cpu"))
+        band = oracle.trace_primary(width, height, row_begin=g.row_begin, row_count=g.rows)
+        g.local[: g.rows].copy_(torch.from_numpy(band.view(np.int32)))
+        image = g.gather()
+        if rank == 0:
+            np.save(out_path, image.numpy().view(np.uint32))
+        else:
+            assert image is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,size", [(2, (128, 72)), (3, (100, 200)), (4, (512, 64))])
+def test_gather_of_bands_rebuilds_reference_image(tmp_path, world, size):
+    width, height = size
+    out = str(tmp_path / "image.npy")
+    mp.spawn(_worker, args=(world, free_port(), width, height, out), nprocs=world, join=True)
+    image = np.load(out)
+    want = next(e["sha256"] for e in META["images"] if (e["width"], e["height"]) == (width, height))
+    assert hashlib.sha256(image.tobytes()).hexdigest() == want
