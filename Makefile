@@ -13,13 +13,22 @@ LIB := raytracer_amd/lib/libhip_raytracer.so
 CLI := raytracer_amd/bin/raytracer_hip
 HOST_SRCS := $(wildcard raytracer_amd/host/*.cpp)
 
-.PHONY: all lib host oracle clean
-all: lib host oracle
+.PHONY: all lib host oracle tools clean
+all: lib host oracle tools
 
 lib: $(LIB)
-$(LIB): raytracer_amd/csrc/hip_raytracer_kernels.hip include/hip_raytracer.h
+$(LIB): raytracer_amd/csrc/hip_raytracer_kernels.hip raytracer_amd/csrc/rt_exact_math.h include/hip_raytracer.h
 	@mkdir -p raytracer_amd/lib
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $<
+
+# GPU-side self checks and microbenchmarks (run on the GPU box by tests / by hand)
+tools: raytracer_amd/bin/check_exact_math tools/bin/valu_peak
+raytracer_amd/bin/check_exact_math: tools/check_exact_math.hip raytracer_amd/csrc/rt_exact_math.h
+	@mkdir -p raytracer_amd/bin
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -o $@ $<
+tools/bin/valu_peak: tools/valu_peak.hip
+	@mkdir -p tools/bin
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -o $@ $<
 
 host: $(CLI)
 $(CLI): $(HOST_SRCS) $(wildcard raytracer_amd/host/*.h) include/hip_raytracer.h $(LIB)

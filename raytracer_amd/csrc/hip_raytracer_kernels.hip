@@ -25,6 +25,7 @@
 #include <new>
 
 #include "hip_raytracer.h"
+#include "rt_exact_math.h"
 
 namespace {
 
@@ -89,7 +90,16 @@ __device__ __forceinline__ float dot3(f3 a, f3 b) {
 template <bool EXACT>
 __device__ __forceinline__ f3 normalize3(f3 v) {
     if constexpr(EXACT) {
-        const float n = __builtin_sqrtf((v.x * v.x + v.y * v.y) + v.z * v.z);
+        const float m = (v.x * v.x + v.y * v.y) + v.z * v.z;
+        if(rt_exact::tame3(v.x, v.y, v.z)) {
+            // same bits as the plain operators below (rt_exact_math.h), one reciprocal shared
+            // by the three divisions
+            const float n = rt_exact::sqrt_tame(m);
+            const float r = rt_exact::refined_rcp(n);
+            return f3{rt_exact::div_with_rcp(v.x, n, r), rt_exact::div_with_rcp(v.y, n, r),
+                      rt_exact::div_with_rcp(v.z, n, r)};
+        }
+        const float n = __builtin_sqrtf(m);
         if(n != 0.0f) {
             v.x = v.x / n;
             v.y = v.y / n;
@@ -497,6 +507,158 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
 }
 
 // ------------------------------------------------------------------------------------------
+// camera pass: the path pass specialised for scenes in which every surface ends the path
+// (all materials NORMAL -- the reference's scene).  Every path is one segment from the camera,
+// so the sample loop is wave-uniform, the per-sphere terms that only depend on the ray origin
+// (oc = C - camera, c = oc.oc - r*r) are computed once per workgroup, and the sample key needs
+// one add and one PCG output permutation per sample:
+//     pcg_hash(pixel + S) = permute((pixel + S)*A + C) = permute((pixel*A + C) + S*A)
+// with pixel*A + C hoisted per pixel and S*A wave-uniform.  Results are the same bits as
+// path_kernel's (exact build) for such scenes.
+// ------------------------------------------------------------------------------------------
+
+struct camera_consts {       // ONE sphere: its constants travel as kernel arguments (SGPRs)
+    float oc[3];
+    float c;
+    float center[3];
+    float pad;
+};
+
+template <bool EXACT, bool ONE>
+__global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_consts cc, const float4 *__restrict__ geom,
+                                                        uint32_t *__restrict__ argb, float4 *__restrict__ rgba,
+                                                        unsigned long long *ray_counter) {
+    __shared__ float4 s_occ[ONE ? 1 : kLdsSpheres];     // oc.xyz, c
+    __shared__ float4 s_ctr[ONE ? 1 : kLdsSpheres];     // centre.xyz, r*r
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t x = blockIdx.x * kTileW + (tid & (kTileW - 1));
+    const uint32_t row = blockIdx.y * kTileH + (tid / kTileW);
+    const uint32_t y = vc.row_begin + row;
+    const bool valid = (x < vc.width) && (row < vc.row_count);
+    const f3 cam = {vc.cam[0], vc.cam[1], vc.cam[2]};
+    const uint32_t n_spheres = ONE ? 1u : vc.n_spheres;
+
+    if constexpr(!ONE) {
+        for(uint32_t i = tid; i < n_spheres; i += kBlock) {
+            const float4 g = geom[i];
+            const f3 oc = {g.x - cam.x, g.y - cam.y, g.z - cam.z};
+            s_occ[i] = make_float4(oc.x, oc.y, oc.z, dot3<EXACT>(oc, oc) - g.w);
+            s_ctr[i] = g;
+        }
+        __syncthreads();
+    }
+
+    if(valid) {
+        const float xf = static_cast<float>(x), yf = static_cast<float>(y);
+        const f3 bg = row_background<EXACT>(vc, y);
+        const uint32_t pixel_lcg = (y * vc.width + x) * 747796405u + 2891336453u;
+        const bool jitter = (vc.flags & AEHIP_FLAG_JITTER) != 0;
+        const float dz_raw = 0.0f - cam.z;
+
+        f3 sum = {0.0f, 0.0f, 0.0f};
+        for(uint32_t sample = 0; sample < vc.spp; sample++) {
+            const uint32_t key = pcg_permute(pixel_lcg + pcg_hash(sample + vc.seed_hash) * 747796405u);
+            // x + j*2^-16: the product is exact, so the fused form rounds once, exactly like the
+            // separate multiply and add
+            const float px = jitter ? __builtin_fmaf(static_cast<float>(key >> 16), 1.0f / 65536.0f, xf) : xf + 0.5f;
+            const float py = jitter ? __builtin_fmaf(static_cast<float>(key & 0xffffu), 1.0f / 65536.0f, yf) : yf + 0.5f;
+            const float uvx = rt_fma<EXACT>(px, vc.psx, -vc.vw_half);
+            const float uvy = rt_fma<EXACT>(py, vc.psy, -vc.vh_half);
+            const f3 draw = {uvx - cam.x, uvy - cam.y, dz_raw};
+
+            f3 L = bg;
+            if constexpr(EXACT) {
+                const f3 d = normalize3<true>(draw);
+                const float a = dot3<true>(d, d);
+                const float a4 = 4.0f * a;
+                const float a2 = 2.0f * a;
+                float closest = 3.402823466e+38f;
+                int hit = -1;
+                for(uint32_t i = 0; i < n_spheres; i++) {
+                    const float4 k = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
+                    const float b = -2.0f * dot3<true>(d, f3{k.x, k.y, k.z});
+                    const float disc = b * b - a4 * k.w;
+                    if(disc >= 0.0f) {
+                        const float sq = __builtin_sqrtf(disc);
+                        float t = (-b - sq) / a2;
+                        bool ok = (t > kTMin) && (t < closest);
+                        if(!ok) {
+                            t = (-b + sq) / a2;
+                            ok = (t > kTMin) && (t < closest);
+                        }
+                        if(ok) {
+                            closest = t;
+                            hit = static_cast<int>(i);
+                        }
+                    }
+                }
+                if(hit >= 0) {
+                    const f3 ctr = ONE ? f3{cc.center[0], cc.center[1], cc.center[2]}
+                                       : f3{s_ctr[hit].x, s_ctr[hit].y, s_ctr[hit].z};
+                    const f3 pt = {d.x * closest + cam.x, d.y * closest + cam.y, d.z * closest + cam.z};
+                    const f3 n = normalize3<true>(f3{pt.x - ctr.x, pt.y - ctr.y, pt.z - ctr.z});
+                    L = f3{remap_unit(n.x), remap_unit(n.y), remap_unit(n.z)};      // throughput is 1
+                }
+            } else {
+                // fast build: the ray is left unnormalised (the hit test is scale invariant);
+                // t runs along `draw`, lengths are recovered only for accepted hits
+                const float dd = dot3<false>(draw, draw);
+                float closest = 3.402823466e+38f;
+                int hit = -1;
+                for(uint32_t i = 0; i < n_spheres; i++) {
+                    const float4 k = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
+                    const float h = dot3<false>(draw, f3{k.x, k.y, k.z});
+                    const float disc = __builtin_fmaf(-dd, k.w, h * h);
+                    if(disc >= 0.0f) {
+                        const float sq = __builtin_amdgcn_sqrtf(disc);
+                        const float inv = __builtin_amdgcn_rcpf(dd);
+                        const float tmin = kTMin * __builtin_amdgcn_rsqf(dd);       // t_min in units of |draw|
+                        float t = (h - sq) * inv;
+                        bool ok = (t > tmin) && (t < closest);
+                        if(!ok) {
+                            t = (h + sq) * inv;
+                            ok = (t > tmin) && (t < closest);
+                        }
+                        if(ok) {
+                            closest = t;
+                            hit = static_cast<int>(i);
+                        }
+                    }
+                }
+                if(hit >= 0) {
+                    const f3 ctr = ONE ? f3{cc.center[0], cc.center[1], cc.center[2]}
+                                       : f3{s_ctr[hit].x, s_ctr[hit].y, s_ctr[hit].z};
+                    const f3 v = {__builtin_fmaf(draw.x, closest, cam.x - ctr.x), __builtin_fmaf(draw.y, closest, cam.y - ctr.y),
+                                  __builtin_fmaf(draw.z, closest, cam.z - ctr.z)};
+                    const float half_inv = 0.5f * __builtin_amdgcn_rsqf(dot3<false>(v, v));
+                    L = f3{__builtin_fmaf(v.x, half_inv, 0.5f), __builtin_fmaf(v.y, half_inv, 0.5f),
+                           __builtin_fmaf(v.z, half_inv, 0.5f)};
+                }
+            }
+            sum.x += L.x;
+            sum.y += L.y;
+            sum.z += L.z;
+        }
+
+        const float n = static_cast<float>(vc.spp);
+        const float r = clamp01(rt_div<EXACT>(sum.x, n));
+        const float g = clamp01(rt_div<EXACT>(sum.y, n));
+        const float b = clamp01(rt_div<EXACT>(sum.z, n));
+        const size_t idx = static_cast<size_t>(row) * vc.width + x;
+        argb[idx] = pack_argb32(r, g, b);
+        if(rgba) rgba[idx] = make_float4(r, g, b, 1.0f);
+    }
+
+    if(vc.flags & AEHIP_FLAG_COUNT_RAYS) {
+        uint32_t v = valid ? vc.spp : 0u;
+#pragma unroll
+        for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if((tid & 63u) == 0) atomicAdd(ray_counter, static_cast<unsigned long long>(v));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side: error reporting, backend object, C ABI
 // ------------------------------------------------------------------------------------------
 
@@ -528,6 +690,8 @@ struct aehip_backend {
     aehip_params params{};
     view_consts vc{};
     float4 sphere0{};                        // primary pass: centre xyz, w = r*r
+    bool all_terminal = false;               // every material ends the path: camera_kernel applies
+    camera_consts cc{};                      // sphere 0 relative to the camera (camera_kernel, ONE)
 
     float4 *d_geom = nullptr;                // n x (cx, cy, cz, r*r)
     float4 *d_matl = nullptr;                // n x (albedo rgb, param)
@@ -564,6 +728,13 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         else if(exact) { func = reinterpret_cast<const void *>(primary_kernel<true, false>); hipLaunchKernelGGL((primary_kernel<true, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->sphere0, argb_dev, rgba); }
         else if(vec4) { func = reinterpret_cast<const void *>(primary_kernel<false, true>); hipLaunchKernelGGL((primary_kernel<false, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->sphere0, argb_dev, rgba); }
         else { func = reinterpret_cast<const void *>(primary_kernel<false, false>); hipLaunchKernelGGL((primary_kernel<false, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->sphere0, argb_dev, rgba); }
+    } else if(b->all_terminal && vc.n_spheres <= static_cast<uint32_t>(kLdsSpheres)) {
+        const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + kTileH - 1) / kTileH);
+        const bool one = vc.n_spheres == 1;
+        if(exact && one) { func = reinterpret_cast<const void *>(camera_kernel<true, true>); hipLaunchKernelGGL((camera_kernel<true, true>), grid, dim3(kBlock), 0, stream, vc, b->cc, b->d_geom, argb_dev, rgba, b->d_rays); }
+        else if(exact) { func = reinterpret_cast<const void *>(camera_kernel<true, false>); hipLaunchKernelGGL((camera_kernel<true, false>), grid, dim3(kBlock), 0, stream, vc, b->cc, b->d_geom, argb_dev, rgba, b->d_rays); }
+        else if(one) { func = reinterpret_cast<const void *>(camera_kernel<false, true>); hipLaunchKernelGGL((camera_kernel<false, true>), grid, dim3(kBlock), 0, stream, vc, b->cc, b->d_geom, argb_dev, rgba, b->d_rays); }
+        else { func = reinterpret_cast<const void *>(camera_kernel<false, false>); hipLaunchKernelGGL((camera_kernel<false, false>), grid, dim3(kBlock), 0, stream, vc, b->cc, b->d_geom, argb_dev, rgba, b->d_rays); }
     } else {
         const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + kTileH - 1) / kTileH);
         const bool single = vc.n_spheres <= static_cast<uint32_t>(kLdsSpheres);
@@ -732,6 +903,17 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
             kind[i] = s.material;
         }
         b->sphere0 = geom[0];
+        b->all_terminal = true;
+        for(uint32_t i = 0; i < n; i++) b->all_terminal = b->all_terminal && kind[i] == AEHIP_MAT_NORMAL;
+        {
+            // sphere 0 as seen from the camera, in the reference's operation order
+            // (src/shapes.cpp:15,18): oc = C - O, c = oc.oc - r*r
+            const float ocx = geom[0].x - vc.cam[0], ocy = geom[0].y - vc.cam[1], ocz = geom[0].z - vc.cam[2];
+            b->cc.oc[0] = ocx; b->cc.oc[1] = ocy; b->cc.oc[2] = ocz;
+            b->cc.c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - geom[0].w;
+            b->cc.center[0] = geom[0].x; b->cc.center[1] = geom[0].y; b->cc.center[2] = geom[0].z;
+            b->cc.pad = 0.0f;
+        }
         hipError_t e = hipMemcpyAsync(b->d_geom, geom, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
         if(e == hipSuccess) e = hipMemcpyAsync(b->d_matl, matl, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
         if(e == hipSuccess) e = hipMemcpyAsync(b->d_kind, kind, sizeof(uint32_t) * n, hipMemcpyHostToDevice, b->stream);
