@@ -153,7 +153,15 @@ void orc_trace_primary(const orc_scene *scene, uint32_t width, uint32_t height,
  * Replaces the reference's stateful xorshift32 (src/random.cpp:18-29, dead code there) by a
  * stream that is a pure function of (seed, absolute pixel index, sample index), so the image
  * does not depend on how pixels are assigned to lanes, workgroups or GPUs.
- * Mixing function: PCG RXS-M-XS 32 (O'Neill), used as a hash and as the per-path generator. */
+ * Mixing function: PCG RXS-M-XS 32 (O'Neill), used as a hash and as the per-path generator.
+ *
+ * Key of path (pixel, sample) = pixel_term + sample_term (mod 2^32):
+ *   sample_term = hash(sample + hash(seed) ^ 0x9e3779b9)   one pseudo-random word per sample
+ *                                                          index, shared by all pixels;
+ *   pixel_term  = hash(pixel  + hash(seed))                a pseudo-random rotation per pixel.
+ * The two 16-bit halves of the key are the sub-pixel offsets, so every pixel sees the same
+ * sample pattern under its own toroidal shift (a Cranley-Patterson rotation): unbiased, and the
+ * per-sample cost on the GPU is one integer add. */
 
 uint32_t orc_pcg_hash(uint32_t v) {
     const uint32_t s = v * 747796405u + 2891336453u;
@@ -161,8 +169,16 @@ uint32_t orc_pcg_hash(uint32_t v) {
     return (w >> 22) ^ w;
 }
 
+uint32_t orc_sample_term(uint32_t seed, uint32_t sample_index) {
+    return orc_pcg_hash(sample_index + (orc_pcg_hash(seed) ^ 0x9e3779b9u));
+}
+
+uint32_t orc_pixel_term(uint32_t seed, uint32_t pixel_index) {
+    return orc_pcg_hash(pixel_index + orc_pcg_hash(seed));
+}
+
 uint32_t orc_path_key(uint32_t seed, uint32_t pixel_index, uint32_t sample_index) {
-    return orc_pcg_hash(pixel_index + orc_pcg_hash(sample_index + orc_pcg_hash(seed)));
+    return orc_pixel_term(seed, pixel_index) + orc_sample_term(seed, sample_index);
 }
 
 /* The path's generator is PCG RXS-M-XS 32 proper: the state starts at the path key, every draw

@@ -81,6 +81,8 @@ double orc_trace_primary_mt(const orc_scene *scene, uint32_t width, uint32_t hei
 
 /* RNG and sampling primitives, exported so tests can pin them individually. */
 uint32_t orc_pcg_hash(uint32_t v);
+uint32_t orc_sample_term(uint32_t seed, uint32_t sample_index);
+uint32_t orc_pixel_term(uint32_t seed, uint32_t pixel_index);
 uint32_t orc_path_key(uint32_t seed, uint32_t pixel_index, uint32_t sample_index);
 uint32_t orc_rng_next(uint32_t *state);
 void orc_cossin_2pi(float u, float *out_cos, float *out_sin);

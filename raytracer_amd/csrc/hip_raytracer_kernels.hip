@@ -159,9 +159,13 @@ __host__ __device__ __forceinline__ uint32_t pcg_permute(uint32_t s) {
 }
 __host__ __device__ __forceinline__ uint32_t pcg_hash(uint32_t v) { return pcg_permute(v * 747796405u + 2891336453u); }
 
-// key of path (pixel, sample): a pure function of absolute pixel index, sample index and seed
-__device__ __forceinline__ uint32_t path_key(uint32_t seed_hash, uint32_t pixel, uint32_t sample) {
-    return pcg_hash(pixel + pcg_hash(sample + seed_hash));
+// Key of path (pixel, sample) = pixel_term + sample_term: a pseudo-random rotation per pixel plus
+// one pseudo-random word per sample index shared by all pixels (a Cranley-Patterson rotation of
+// one sample pattern).  The sample terms are tabulated by the host (sample_terms[], read through
+// the scalar cache), so a new sample costs the vector unit one integer add.
+__host__ __device__ __forceinline__ uint32_t pixel_term(uint32_t seed_hash, uint32_t pixel) { return pcg_hash(pixel + seed_hash); }
+__host__ __device__ __forceinline__ uint32_t sample_term(uint32_t seed_hash, uint32_t sample) {
+    return pcg_hash(sample + (seed_hash ^ 0x9e3779b9u));
 }
 __device__ __forceinline__ uint32_t rng_next(uint32_t &state) {
     state = state * 747796405u + 2891336453u;
@@ -290,8 +294,9 @@ struct path_state {
 };
 
 template <bool EXACT>
-__device__ __forceinline__ void start_path(const view_consts &vc, uint32_t x, uint32_t y, uint32_t sample, path_state &ps) {
-    const uint32_t key = path_key(vc.seed_hash, y * vc.width + x, sample);
+__device__ __forceinline__ void start_path(const view_consts &vc, uint32_t pix_term, const uint32_t *__restrict__ sample_terms,
+                                           uint32_t x, uint32_t y, uint32_t sample, path_state &ps) {
+    const uint32_t key = pix_term + sample_terms[sample];
     float jx = 0.5f, jy = 0.5f;
     if(vc.flags & AEHIP_FLAG_JITTER) {
         jx = static_cast<float>(key >> 16) * (1.0f / 65536.0f);
@@ -423,7 +428,8 @@ __device__ __forceinline__ bool shade_segment(const view_consts &vc, uint32_t y,
 template <bool EXACT, bool SINGLE_CHUNK>
 __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const float4 *__restrict__ geom,
                                                       const float4 *__restrict__ matl,
-                                                      const uint32_t *__restrict__ kind, uint32_t *__restrict__ argb,
+                                                      const uint32_t *__restrict__ kind,
+                                                      const uint32_t *__restrict__ sample_terms, uint32_t *__restrict__ argb,
                                                       float4 *__restrict__ rgba, unsigned long long *ray_counter) {
     __shared__ float4 s_geom[kLdsSpheres];
 
@@ -446,7 +452,8 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
     ps.o = ps.d = ps.thr = f3{0.0f, 0.0f, 0.0f};
     ps.rng = 0;
     ps.bounce = 0;
-    if(alive) start_path<EXACT>(vc, x, y, 0, ps);
+    const uint32_t pix_term = pixel_term(vc.seed_hash, y * vc.width + x);
+    if(alive) start_path<EXACT>(vc, pix_term, sample_terms, x, y, 0, ps);
 
     for(;;) {
         if constexpr(SINGLE_CHUNK) {
@@ -481,7 +488,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
                 sum.y += L.y;
                 sum.z += L.z;
                 sample++;
-                if(sample < vc.spp) start_path<EXACT>(vc, x, y, sample, ps);
+                if(sample < vc.spp) start_path<EXACT>(vc, pix_term, sample_terms, x, y, sample, ps);
                 else alive = false;
             }
         }
@@ -510,11 +517,9 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
 // camera pass: the path pass specialised for scenes in which every surface ends the path
 // (all materials NORMAL -- the reference's scene).  Every path is one segment from the camera,
 // so the sample loop is wave-uniform, the per-sphere terms that only depend on the ray origin
-// (oc = C - camera, c = oc.oc - r*r) are computed once per workgroup, and the sample key needs
-// one add and one PCG output permutation per sample:
-//     pcg_hash(pixel + S) = permute((pixel + S)*A + C) = permute((pixel*A + C) + S*A)
-// with pixel*A + C hoisted per pixel and S*A wave-uniform.  Results are the same bits as
-// path_kernel's (exact build) for such scenes.
+// (oc = C - camera, c = oc.oc - r*r) are computed once per workgroup, and the sample key is the
+// per-pixel term plus the tabulated per-sample term, fetched through the scalar cache one
+// iteration ahead.  Results are the same bits as path_kernel's (exact build) for such scenes.
 // ------------------------------------------------------------------------------------------
 
 struct camera_consts {       // ONE sphere: its constants travel as kernel arguments (SGPRs)
@@ -526,6 +531,7 @@ struct camera_consts {       // ONE sphere: its constants travel as kernel argum
 
 template <bool EXACT, bool ONE>
 __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_consts cc, const float4 *__restrict__ geom,
+                                                        const uint32_t *__restrict__ sample_terms,
                                                         uint32_t *__restrict__ argb, float4 *__restrict__ rgba,
                                                         unsigned long long *ray_counter) {
     __shared__ float4 s_occ[ONE ? 1 : kLdsSpheres];     // oc.xyz, c
@@ -550,65 +556,104 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
     }
 
     if(valid) {
-        const float xf = static_cast<float>(x), yf = static_cast<float>(y);
         const f3 bg = row_background<EXACT>(vc, y);
-        const uint32_t pixel_lcg = (y * vc.width + x) * 747796405u + 2891336453u;
+        const uint32_t pix_term = pixel_term(vc.seed_hash, y * vc.width + x);
+        // sample position = base + draw * scale: (2^-16, +0) with jitter, (0, +0.5) without.
+        // Both products are exact, so the fused form rounds once, like multiply-then-add.
         const bool jitter = (vc.flags & AEHIP_FLAG_JITTER) != 0;
-        const float dz_raw = 0.0f - cam.z;
+        const float jscale = jitter ? (1.0f / 65536.0f) : 0.0f;
+        const float xb = static_cast<float>(x) + (jitter ? 0.0f : 0.5f);
+        const float yb = static_cast<float>(y) + (jitter ? 0.0f : 0.5f);
+        const float dz = 0.0f - cam.z;
 
         f3 sum = {0.0f, 0.0f, 0.0f};
-        for(uint32_t sample = 0; sample < vc.spp; sample++) {
-            const uint32_t key = pcg_permute(pixel_lcg + pcg_hash(sample + vc.seed_hash) * 747796405u);
-            // x + j*2^-16: the product is exact, so the fused form rounds once, exactly like the
-            // separate multiply and add
-            const float px = jitter ? __builtin_fmaf(static_cast<float>(key >> 16), 1.0f / 65536.0f, xf) : xf + 0.5f;
-            const float py = jitter ? __builtin_fmaf(static_cast<float>(key & 0xffffu), 1.0f / 65536.0f, yf) : yf + 0.5f;
-            const float uvx = rt_fma<EXACT>(px, vc.psx, -vc.vw_half);
-            const float uvy = rt_fma<EXACT>(py, vc.psy, -vc.vh_half);
-            const f3 draw = {uvx - cam.x, uvy - cam.y, dz_raw};
 
-            f3 L = bg;
-            if constexpr(EXACT) {
-                const f3 d = normalize3<true>(draw);
-                const float a = dot3<true>(d, d);
-                const float a4 = 4.0f * a;
-                const float a2 = 2.0f * a;
-                float closest = 3.402823466e+38f;
-                int hit = -1;
+        if constexpr(EXACT) {
+            uint32_t term = sample_terms[0];
+            for(uint32_t sample = 0; sample < vc.spp; sample++) {
+                const uint32_t key = pix_term + term;
+                term = sample_terms[sample + 1];        // next sample's term (table has one spare entry)
+                const float px = __builtin_fmaf(static_cast<float>(key >> 16), jscale, xb);
+                const float py = __builtin_fmaf(static_cast<float>(key & 0xffffu), jscale, yb);
+                const float uvx = px * vc.psx - vc.vw_half;
+                const float uvy = py * vc.psy - vc.vh_half;
+                const f3 draw = {uvx - cam.x, uvy - cam.y, dz};
+
+                // Conservative miss test on the unnormalised ray in fused arithmetic.  With
+                // h = draw.oc and dd = draw.draw the reference's discriminant has the sign of
+                // h*h - dd*c; both evaluations carry relative rounding error of order 1e-6 of
+                // (h*h + |dd*c|), so a value below -1e-4 of that sum is negative in the exact
+                // evaluation as well, and the sample takes the row background whatever its
+                // direction is.  Everything else runs the exact arithmetic below.
+                const float dd = __builtin_fmaf(draw.z, draw.z, __builtin_fmaf(draw.y, draw.y, draw.x * draw.x));
+                bool maybe = false;
                 for(uint32_t i = 0; i < n_spheres; i++) {
                     const float4 k = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
-                    const float b = -2.0f * dot3<true>(d, f3{k.x, k.y, k.z});
-                    const float disc = b * b - a4 * k.w;
-                    if(disc >= 0.0f) {
-                        const float sq = __builtin_sqrtf(disc);
-                        float t = (-b - sq) / a2;
-                        bool ok = (t > kTMin) && (t < closest);
-                        if(!ok) {
-                            t = (-b + sq) / a2;
-                            ok = (t > kTMin) && (t < closest);
-                        }
-                        if(ok) {
-                            closest = t;
-                            hit = static_cast<int>(i);
+                    const float h = __builtin_fmaf(draw.z, k.z, __builtin_fmaf(draw.y, k.y, draw.x * k.x));
+                    const float q = h * h, e = dd * k.w;
+                    const float scale = q + __builtin_fabsf(e);
+                    maybe = maybe || !((q - e) < -1e-4f * scale) || !(scale < 1e30f);
+                }
+
+                f3 L = bg;
+                if(maybe) {
+                    const f3 d = normalize3<true>(draw);
+                    const float a = dot3<true>(d, d);
+                    const float a4 = 4.0f * a;
+                    const float a2 = 2.0f * a;
+                    float closest = 3.402823466e+38f;
+                    int hit = -1;
+                    for(uint32_t i = 0; i < n_spheres; i++) {
+                        const float4 k = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
+                        const float b = -2.0f * dot3<true>(d, f3{k.x, k.y, k.z});
+                        const float disc = b * b - a4 * k.w;
+                        if(disc >= 0.0f) {
+                            const float sq = __builtin_sqrtf(disc);
+                            float t = (-b - sq) / a2;
+                            bool ok = (t > kTMin) && (t < closest);
+                            if(!ok) {
+                                t = (-b + sq) / a2;
+                                ok = (t > kTMin) && (t < closest);
+                            }
+                            if(ok) {
+                                closest = t;
+                                hit = static_cast<int>(i);
+                            }
                         }
                     }
+                    if(hit >= 0) {
+                        const f3 ctr = ONE ? f3{cc.center[0], cc.center[1], cc.center[2]}
+                                           : f3{s_ctr[hit].x, s_ctr[hit].y, s_ctr[hit].z};
+                        const f3 pt = {d.x * closest + cam.x, d.y * closest + cam.y, d.z * closest + cam.z};
+                        const f3 n = normalize3<true>(f3{pt.x - ctr.x, pt.y - ctr.y, pt.z - ctr.z});
+                        L = f3{remap_unit(n.x), remap_unit(n.y), remap_unit(n.z)};      // throughput is 1
+                    }
                 }
-                if(hit >= 0) {
-                    const f3 ctr = ONE ? f3{cc.center[0], cc.center[1], cc.center[2]}
-                                       : f3{s_ctr[hit].x, s_ctr[hit].y, s_ctr[hit].z};
-                    const f3 pt = {d.x * closest + cam.x, d.y * closest + cam.y, d.z * closest + cam.z};
-                    const f3 n = normalize3<true>(f3{pt.x - ctr.x, pt.y - ctr.y, pt.z - ctr.z});
-                    L = f3{remap_unit(n.x), remap_unit(n.y), remap_unit(n.z)};      // throughput is 1
-                }
-            } else {
-                // fast build: the ray is left unnormalised (the hit test is scale invariant);
-                // t runs along `draw`, lengths are recovered only for accepted hits
-                const float dd = dot3<false>(draw, draw);
+                sum.x += L.x;
+                sum.y += L.y;
+                sum.z += L.z;
+            }
+        } else {
+            // fast build: the ray stays unnormalised (the hit test is scale invariant, t runs
+            // along `draw`); per-pixel terms of the sample position are folded into one fma;
+            // only hits add to the sum, misses are counted and added as (misses * background)
+            const float ux0 = __builtin_fmaf(xb, vc.psx, -(vc.vw_half + cam.x));
+            const float uy0 = __builtin_fmaf(yb, vc.psy, -(vc.vh_half + cam.y));
+            const float sx = jscale * vc.psx, sy = jscale * vc.psy;
+            const float dz2 = dz * dz;
+            uint32_t hits = 0;
+            uint32_t term = sample_terms[0];
+            for(uint32_t sample = 0; sample < vc.spp; sample++) {
+                const uint32_t key = pix_term + term;
+                term = sample_terms[sample + 1];        // next sample's term (table has one spare entry)
+                const float dx = __builtin_fmaf(static_cast<float>(key >> 16), sx, ux0);
+                const float dy = __builtin_fmaf(static_cast<float>(key & 0xffffu), sy, uy0);
+                const float dd = __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, dz2));
                 float closest = 3.402823466e+38f;
                 int hit = -1;
                 for(uint32_t i = 0; i < n_spheres; i++) {
                     const float4 k = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
-                    const float h = dot3<false>(draw, f3{k.x, k.y, k.z});
+                    const float h = __builtin_fmaf(dy, k.y, __builtin_fmaf(dx, k.x, dz * k.z));
                     const float disc = __builtin_fmaf(-dd, k.w, h * h);
                     if(disc >= 0.0f) {
                         const float sq = __builtin_amdgcn_sqrtf(disc);
@@ -629,16 +674,19 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
                 if(hit >= 0) {
                     const f3 ctr = ONE ? f3{cc.center[0], cc.center[1], cc.center[2]}
                                        : f3{s_ctr[hit].x, s_ctr[hit].y, s_ctr[hit].z};
-                    const f3 v = {__builtin_fmaf(draw.x, closest, cam.x - ctr.x), __builtin_fmaf(draw.y, closest, cam.y - ctr.y),
-                                  __builtin_fmaf(draw.z, closest, cam.z - ctr.z)};
+                    const f3 v = {__builtin_fmaf(dx, closest, cam.x - ctr.x), __builtin_fmaf(dy, closest, cam.y - ctr.y),
+                                  __builtin_fmaf(dz, closest, cam.z - ctr.z)};
                     const float half_inv = 0.5f * __builtin_amdgcn_rsqf(dot3<false>(v, v));
-                    L = f3{__builtin_fmaf(v.x, half_inv, 0.5f), __builtin_fmaf(v.y, half_inv, 0.5f),
-                           __builtin_fmaf(v.z, half_inv, 0.5f)};
+                    sum.x += __builtin_fmaf(v.x, half_inv, 0.5f);
+                    sum.y += __builtin_fmaf(v.y, half_inv, 0.5f);
+                    sum.z += __builtin_fmaf(v.z, half_inv, 0.5f);
+                    hits++;
                 }
             }
-            sum.x += L.x;
-            sum.y += L.y;
-            sum.z += L.z;
+            const float misses = static_cast<float>(vc.spp - hits);
+            sum.x = __builtin_fmaf(misses, bg.x, sum.x);
+            sum.y = __builtin_fmaf(misses, bg.y, sum.y);
+            sum.z = __builtin_fmaf(misses, bg.z, sum.z);
         }
 
         const float n = static_cast<float>(vc.spp);
@@ -703,6 +751,8 @@ struct aehip_backend {
     uint32_t *h_staging = nullptr;           // pinned
     size_t staging_capacity = 0;
     unsigned long long *d_rays = nullptr;
+    uint32_t *d_sample_terms = nullptr;      // spp + 1 words: per-sample key terms (+1 spare for prefetch)
+    uint32_t sample_terms_capacity = 0;
 
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_copy = nullptr;
@@ -731,17 +781,17 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
     } else if(b->all_terminal && vc.n_spheres <= static_cast<uint32_t>(kLdsSpheres)) {
         const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + kTileH - 1) / kTileH);
         const bool one = vc.n_spheres == 1;
-        if(exact && one) { func = reinterpret_cast<const void *>(camera_kernel<true, true>); hipLaunchKernelGGL((camera_kernel<true, true>), grid, dim3(kBlock), 0, stream, vc, b->cc, b->d_geom, argb_dev, rgba, b->d_rays); }
-        else if(exact) { func = reinterpret_cast<const void *>(camera_kernel<true, false>); hipLaunchKernelGGL((camera_kernel<true, false>), grid, dim3(kBlock), 0, stream, vc, b->cc, b->d_geom, argb_dev, rgba, b->d_rays); }
-        else if(one) { func = reinterpret_cast<const void *>(camera_kernel<false, true>); hipLaunchKernelGGL((camera_kernel<false, true>), grid, dim3(kBlock), 0, stream, vc, b->cc, b->d_geom, argb_dev, rgba, b->d_rays); }
-        else { func = reinterpret_cast<const void *>(camera_kernel<false, false>); hipLaunchKernelGGL((camera_kernel<false, false>), grid, dim3(kBlock), 0, stream, vc, b->cc, b->d_geom, argb_dev, rgba, b->d_rays); }
+        if(exact && one) { func = reinterpret_cast<const void *>(camera_kernel<true, true>); hipLaunchKernelGGL((camera_kernel<true, true>), grid, dim3(kBlock), 0, stream, vc, b->cc, b->d_geom, b->d_sample_terms, argb_dev, rgba, b->d_rays); }
+        else if(exact) { func = reinterpret_cast<const void *>(camera_kernel<true, false>); hipLaunchKernelGGL((camera_kernel<true, false>), grid, dim3(kBlock), 0, stream, vc, b->cc, b->d_geom, b->d_sample_terms, argb_dev, rgba, b->d_rays); }
+        else if(one) { func = reinterpret_cast<const void *>(camera_kernel<false, true>); hipLaunchKernelGGL((camera_kernel<false, true>), grid, dim3(kBlock), 0, stream, vc, b->cc, b->d_geom, b->d_sample_terms, argb_dev, rgba, b->d_rays); }
+        else { func = reinterpret_cast<const void *>(camera_kernel<false, false>); hipLaunchKernelGGL((camera_kernel<false, false>), grid, dim3(kBlock), 0, stream, vc, b->cc, b->d_geom, b->d_sample_terms, argb_dev, rgba, b->d_rays); }
     } else {
         const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + kTileH - 1) / kTileH);
         const bool single = vc.n_spheres <= static_cast<uint32_t>(kLdsSpheres);
-        if(exact && single) { func = reinterpret_cast<const void *>(path_kernel<true, true>); hipLaunchKernelGGL((path_kernel<true, true>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind, argb_dev, rgba, b->d_rays); }
-        else if(exact) { func = reinterpret_cast<const void *>(path_kernel<true, false>); hipLaunchKernelGGL((path_kernel<true, false>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind, argb_dev, rgba, b->d_rays); }
-        else if(single) { func = reinterpret_cast<const void *>(path_kernel<false, true>); hipLaunchKernelGGL((path_kernel<false, true>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind, argb_dev, rgba, b->d_rays); }
-        else { func = reinterpret_cast<const void *>(path_kernel<false, false>); hipLaunchKernelGGL((path_kernel<false, false>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind, argb_dev, rgba, b->d_rays); }
+        if(exact && single) { func = reinterpret_cast<const void *>(path_kernel<true, true>); hipLaunchKernelGGL((path_kernel<true, true>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind, b->d_sample_terms, argb_dev, rgba, b->d_rays); }
+        else if(exact) { func = reinterpret_cast<const void *>(path_kernel<true, false>); hipLaunchKernelGGL((path_kernel<true, false>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind, b->d_sample_terms, argb_dev, rgba, b->d_rays); }
+        else if(single) { func = reinterpret_cast<const void *>(path_kernel<false, true>); hipLaunchKernelGGL((path_kernel<false, true>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind, b->d_sample_terms, argb_dev, rgba, b->d_rays); }
+        else { func = reinterpret_cast<const void *>(path_kernel<false, false>); hipLaunchKernelGGL((path_kernel<false, false>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind, b->d_sample_terms, argb_dev, rgba, b->d_rays); }
     }
     AEHIP_CHECK(hipGetLastError());
 
@@ -818,6 +868,7 @@ void aehip_backend_destroy(aehip_backend *b) {
     if(b->d_kind) (void)hipFree(b->d_kind);
     if(b->d_argb) (void)hipFree(b->d_argb);
     if(b->d_rays) (void)hipFree(b->d_rays);
+    if(b->d_sample_terms) (void)hipFree(b->d_sample_terms);
     if(b->h_staging) (void)hipHostFree(b->h_staging);
     if(b->ev_begin) (void)hipEventDestroy(b->ev_begin);
     if(b->ev_end) (void)hipEventDestroy(b->ev_end);
@@ -920,6 +971,24 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
         if(e == hipSuccess) e = hipStreamSynchronize(b->stream);
         std::free(geom); std::free(matl); std::free(kind);
         if(e != hipSuccess) return fail(AEHIP_E_HIP, "scene upload: %s", hipGetErrorString(e));
+    }
+
+    // per-sample key terms
+    {
+        const uint32_t count = p.spp + 1;
+        if(count > b->sample_terms_capacity) {
+            if(b->d_sample_terms) (void)hipFree(b->d_sample_terms);
+            b->d_sample_terms = nullptr; b->sample_terms_capacity = 0;
+            AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_sample_terms), sizeof(uint32_t) * count));
+            b->sample_terms_capacity = count;
+        }
+        uint32_t *terms = static_cast<uint32_t *>(std::malloc(sizeof(uint32_t) * count));
+        if(!terms) return fail(AEHIP_E_INVALID, "out of host memory for %u sample terms", count);
+        for(uint32_t i = 0; i < count; i++) terms[i] = sample_term(vc.seed_hash, i);
+        hipError_t e = hipMemcpyAsync(b->d_sample_terms, terms, sizeof(uint32_t) * count, hipMemcpyHostToDevice, b->stream);
+        if(e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        std::free(terms);
+        if(e != hipSuccess) return fail(AEHIP_E_HIP, "sample term upload: %s", hipGetErrorString(e));
     }
 
     b->params = p;
