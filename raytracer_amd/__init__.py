@@ -176,9 +176,10 @@ class HipRaytracer:
         self.params = None
 
     def setup(self, width, height, spp=1, max_depth=1, seed=1, flags=0, pass_=PASS_PRIMARY, row_begin=0,
-              row_count=0, spheres=None, **scene_kw) -> bool:
+              row_count=0, spheres=None, list_source=0, **scene_kw) -> bool:
         sc, keep = make_scene(spheres, **scene_kw)
         p = AehipParams(width, height, row_begin, row_count, spp, max_depth, seed, flags, pass_)
+        p.reserved[0] = list_source      # 0 = library's choice, 1 = LDS staging, 2 = scalar-cache stream
         rc = self._lib.aehip_backend_setup(self._h, ctypes.byref(sc), ctypes.byref(p))
         del keep
         self.params = p

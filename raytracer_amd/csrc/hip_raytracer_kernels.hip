@@ -309,31 +309,126 @@ __device__ __forceinline__ void start_path(const view_consts &vc, uint32_t pix_t
     ps.thr = f3{1.0f, 1.0f, 1.0f};
 }
 
-// Tests the ray against spheres [0,count) of an LDS chunk (sphere = centre xyz, w = r*r).
+// Ray-sphere screening and resolution against an LDS chunk (sphere = centre xyz, w = r*r).
+//
+// The list is walked four spheres at a time: four LDS reads issued together, four screening
+// values computed with no branch between them, ONE branch per group on their maximum, and the
+// expensive part (square root, division, range tests) only for the spheres that passed.
+//
+// Screening value, >= 0 means "may be hit":
+//   fast build:  the discriminant itself in half-b form with a = d.d taken as 1 (d is
+//                normalised): h*h - c, h = d.oc, c = oc.oc - r*r, all fused.
+//   exact build: the same fused value plus a margin, h*h - c + 3e-5*(h*h + oc.oc + r*r).  A
+//                quarter of the exact discriminant b*b - 4ac (src/shapes.cpp:15-20) and this
+//                fused h*h - c are two roundings of the same real number; each is off by at
+//                most about a dozen unit roundoffs (6e-8) of the magnitudes that enter it,
+//                h*h + oc.oc + r*r -- the sum before the cancellation, so the bound also holds
+//                for rays that start on the sphere they test (c ~ 0).  The margin is ~20x that
+//                bound, so a negative screening value implies a negative exact discriminant:
+//                the sphere cannot change the result.  Spheres that pass are resolved with the
+//                reference's operation order, which decides.
+constexpr float kScreenMargin = 3e-5f;
+
+template <bool EXACT>
+__device__ __forceinline__ float screen_sphere(const float4 g, const f3 o, const f3 d, float &h_out) {
+    const f3 oc = {g.x - o.x, g.y - o.y, g.z - o.z};
+    const float h = __builtin_fmaf(d.z, oc.z, __builtin_fmaf(d.y, oc.y, d.x * oc.x));
+    const float c = __builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, __builtin_fmaf(oc.x, oc.x, -g.w)));
+    h_out = h;
+    const float disc = __builtin_fmaf(h, h, -c);
+    if constexpr(EXACT) {
+        const float magnitude = __builtin_fmaf(h, h, __builtin_fmaf(g.w, 2.0f, c));     // h*h + oc.oc + r*r
+        return __builtin_fmaf(kScreenMargin, magnitude, disc);
+    } else {
+        return disc;
+    }
+}
+
 // Quadratic as src/shapes.cpp:14-23 with a (t_min, closest) range test and the far root added.
 template <bool EXACT>
-__device__ __forceinline__ void intersect_chunk(const float4 *__restrict__ s_geom, uint32_t count, uint32_t index_base,
-                                                const f3 o, const f3 d, float a2, float a4, float &closest, int &hit) {
-#pragma unroll 4
-    for(uint32_t i = 0; i < count; i++) {
-        const float4 g = s_geom[i];
+__device__ __forceinline__ void resolve_sphere(const float4 g, int index, float screen, float h, const f3 o, const f3 d,
+                                               float a2, float a4, float &closest, int &hit) {
+    if(!(screen >= 0.0f)) return;
+    float t_near, t_far;
+    if constexpr(EXACT) {
         const f3 oc = {g.x - o.x, g.y - o.y, g.z - o.z};
-        const float b = -2.0f * dot3<EXACT>(d, oc);
-        const float c = dot3<EXACT>(oc, oc) - g.w;
-        const float disc = rt_fma<EXACT>(-a4, c, b * b);
-        if(disc >= 0.0f) {
-            const float sq = rt_sqrt<EXACT>(disc);
-            float t = rt_div<EXACT>(-b - sq, a2);
-            bool ok = (t > kTMin) && (t < closest);
-            if(!ok) {
-                t = rt_div<EXACT>(-b + sq, a2);
-                ok = (t > kTMin) && (t < closest);
-            }
-            if(ok) {
-                closest = t;
-                hit = static_cast<int>(index_base + i);
-            }
+        const float b = -2.0f * dot3<true>(d, oc);
+        const float c = dot3<true>(oc, oc) - g.w;
+        const float disc = b * b - a4 * c;
+        if(!(disc >= 0.0f)) return;
+        const float sq = __builtin_sqrtf(disc);
+        t_near = (-b - sq) / a2;
+        t_far = (-b + sq) / a2;
+    } else {
+        const float sq = __builtin_amdgcn_sqrtf(screen);
+        t_near = h - sq;
+        t_far = h + sq;
+    }
+    float t = t_near;
+    bool ok = (t > kTMin) && (t < closest);
+    if(!ok) {
+        t = t_far;
+        ok = (t > kTMin) && (t < closest);
+    }
+    if(ok) {
+        closest = t;
+        hit = index;
+    }
+}
+
+struct sphere_group {
+    float4 g0, g1, g2, g3;
+};
+
+__device__ __forceinline__ sphere_group load_group(const float4 *__restrict__ list, uint32_t group) {
+    const float4 *p = list + group * 4u;
+    return sphere_group{p[0], p[1], p[2], p[3]};
+}
+
+template <bool EXACT>
+__device__ __forceinline__ void test_group(const sphere_group &sg, int index, const f3 o, const f3 d, float a2, float a4,
+                                           float &closest, int &hit) {
+    float h0, h1, h2, h3;
+    const float k0 = screen_sphere<EXACT>(sg.g0, o, d, h0);
+    const float k1 = screen_sphere<EXACT>(sg.g1, o, d, h1);
+    const float k2 = screen_sphere<EXACT>(sg.g2, o, d, h2);
+    const float k3 = screen_sphere<EXACT>(sg.g3, o, d, h3);
+    if(__builtin_fmaxf(__builtin_fmaxf(k0, k1), __builtin_fmaxf(k2, k3)) >= 0.0f) {
+        resolve_sphere<EXACT>(sg.g0, index, k0, h0, o, d, a2, a4, closest, hit);
+        resolve_sphere<EXACT>(sg.g1, index + 1, k1, h1, o, d, a2, a4, closest, hit);
+        resolve_sphere<EXACT>(sg.g2, index + 2, k2, h2, o, d, a2, a4, closest, hit);
+        resolve_sphere<EXACT>(sg.g3, index + 3, k3, h3, o, d, a2, a4, closest, hit);
+    }
+}
+
+// `list` is either the LDS chunk or (scalar mode) the list in global memory read with a
+// wave-uniform index.  Groups are fetched one ahead of the group being tested, alternating two
+// register sets so no copies are needed: the fetch of group g+1 is in flight while group g is
+// screened.
+template <bool EXACT>
+__device__ __forceinline__ void intersect_chunk(const float4 *__restrict__ list, uint32_t count, uint32_t index_base,
+                                                const f3 o, const f3 d, float a2, float a4, float &closest, int &hit) {
+    const uint32_t groups = count / 4u;
+    uint32_t g = 0;
+    if(groups > 0) {
+        sphere_group A = load_group(list, 0);
+        while(g + 2 <= groups) {
+            const sphere_group B = load_group(list, g + 1);
+            test_group<EXACT>(A, static_cast<int>(index_base + g * 4u), o, d, a2, a4, closest, hit);
+            A = load_group(list, min(g + 2, groups - 1));      // clamped: the last fetch may repeat a group
+            test_group<EXACT>(B, static_cast<int>(index_base + (g + 1) * 4u), o, d, a2, a4, closest, hit);
+            g += 2;
         }
+        if(g < groups) {
+            test_group<EXACT>(A, static_cast<int>(index_base + g * 4u), o, d, a2, a4, closest, hit);
+            g++;
+        }
+    }
+    for(uint32_t i = g * 4u; i < count; i++) {
+        const float4 s = list[i];
+        float h;
+        const float k = screen_sphere<EXACT>(s, o, d, h);
+        resolve_sphere<EXACT>(s, static_cast<int>(index_base + i), k, h, o, d, a2, a4, closest, hit);
     }
 }
 
@@ -422,16 +517,25 @@ __device__ __forceinline__ bool shade_segment(const view_consts &vc, uint32_t y,
 // starts the pixel's next sample (path regeneration), so a wave only idles lanes whose pixel is
 // complete.  The sum over samples is therefore sequential per pixel whatever the divergence.
 //
-// SINGLE_CHUNK: the whole shape list fits the LDS buffer and is staged once; no barrier inside
-// the segment loop, each wave leaves when its own lanes are done.  Otherwise the list streams
-// through LDS in chunks and the workgroup iterates segments together.
-template <bool EXACT, bool SINGLE_CHUNK>
+// Where the shape list is read from (LIST):
+//   kListLdsOnce    the whole list fits the LDS buffer and is staged once; no barrier inside the
+//                   segment loop, each wave leaves when its own lanes are done;
+//   kListLdsChunked the list streams through the LDS buffer in chunks and the workgroup
+//                   iterates segments together (a barrier pair per chunk);
+//   kListScalar     no LDS: the sphere index is wave-uniform, so the list is read straight from
+//                   global memory through the scalar cache into SGPRs (s_load_dwordx4..x16);
+//                   waves stay independent for any list length and occupancy is not capped by
+//                   the LDS allocation.
+constexpr int kListLdsOnce = 0, kListLdsChunked = 1, kListScalar = 2;
+
+template <bool EXACT, int LIST>
 __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const float4 *__restrict__ geom,
                                                       const float4 *__restrict__ matl,
                                                       const uint32_t *__restrict__ kind,
                                                       const uint32_t *__restrict__ sample_terms, uint32_t *__restrict__ argb,
                                                       float4 *__restrict__ rgba, unsigned long long *ray_counter) {
-    __shared__ float4 s_geom[kLdsSpheres];
+    constexpr bool SINGLE_CHUNK = LIST != kListLdsChunked;      // no workgroup barrier in the loop
+    __shared__ float4 s_geom[LIST == kListScalar ? 1 : kLdsSpheres];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t x = blockIdx.x * kTileW + (tid & (kTileW - 1));
@@ -439,7 +543,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
     const uint32_t y = vc.row_begin + row;
     const bool valid = (x < vc.width) && (row < vc.row_count);
 
-    if constexpr(SINGLE_CHUNK) {
+    if constexpr(LIST == kListLdsOnce) {
         for(uint32_t i = tid; i < vc.n_spheres; i += kBlock) s_geom[i] = geom[i];
         __syncthreads();
     }
@@ -468,8 +572,10 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
         float closest = 3.402823466e+38f;
         int hit = -1;
 
-        if constexpr(SINGLE_CHUNK) {
+        if constexpr(LIST == kListLdsOnce) {
             if(alive) intersect_chunk<EXACT>(s_geom, vc.n_spheres, 0, ps.o, ps.d, a2, a4, closest, hit);
+        } else if constexpr(LIST == kListScalar) {
+            if(alive) intersect_chunk<EXACT>(geom, vc.n_spheres, 0, ps.o, ps.d, a2, a4, closest, hit);
         } else {
             for(uint32_t base = 0; base < vc.n_spheres; base += kLdsSpheres) {
                 const uint32_t count = min(static_cast<uint32_t>(kLdsSpheres), vc.n_spheres - base);
@@ -524,9 +630,9 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
 
 struct camera_consts {       // ONE sphere: its constants travel as kernel arguments (SGPRs)
     float oc[3];
-    float c;
+    float c;                 // oc.oc - r*r
     float center[3];
-    float pad;
+    float magnitude;         // oc.oc + r*r: size of the terms behind c, for the screening margin
 };
 
 template <bool EXACT, bool ONE>
@@ -535,7 +641,7 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
                                                         uint32_t *__restrict__ argb, float4 *__restrict__ rgba,
                                                         unsigned long long *ray_counter) {
     __shared__ float4 s_occ[ONE ? 1 : kLdsSpheres];     // oc.xyz, c
-    __shared__ float4 s_ctr[ONE ? 1 : kLdsSpheres];     // centre.xyz, r*r
+    __shared__ float4 s_ctr[ONE ? 1 : kLdsSpheres];     // centre.xyz, oc.oc + r*r
 
     const uint32_t tid = threadIdx.x;
     const uint32_t x = blockIdx.x * kTileW + (tid & (kTileW - 1));
@@ -549,8 +655,9 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
         for(uint32_t i = tid; i < n_spheres; i += kBlock) {
             const float4 g = geom[i];
             const f3 oc = {g.x - cam.x, g.y - cam.y, g.z - cam.z};
-            s_occ[i] = make_float4(oc.x, oc.y, oc.z, dot3<EXACT>(oc, oc) - g.w);
-            s_ctr[i] = g;
+            const float occ = dot3<EXACT>(oc, oc);
+            s_occ[i] = make_float4(oc.x, oc.y, oc.z, occ - g.w);
+            s_ctr[i] = make_float4(g.x, g.y, g.z, occ + g.w);
         }
         __syncthreads();
     }
@@ -581,18 +688,20 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
 
                 // Conservative miss test on the unnormalised ray in fused arithmetic.  With
                 // h = draw.oc and dd = draw.draw the reference's discriminant has the sign of
-                // h*h - dd*c; both evaluations carry relative rounding error of order 1e-6 of
-                // (h*h + |dd*c|), so a value below -1e-4 of that sum is negative in the exact
-                // evaluation as well, and the sample takes the row background whatever its
-                // direction is.  Everything else runs the exact arithmetic below.
+                // h*h - dd*c.  Both evaluations are within about a dozen unit roundoffs of
+                // h*h + dd*(oc.oc + r*r), so a value below -kScreenMargin of that magnitude is
+                // negative in the exact evaluation as well, and the sample takes the row
+                // background whatever its direction is.  Everything else runs the exact
+                // arithmetic below.
                 const float dd = __builtin_fmaf(draw.z, draw.z, __builtin_fmaf(draw.y, draw.y, draw.x * draw.x));
                 bool maybe = false;
                 for(uint32_t i = 0; i < n_spheres; i++) {
                     const float4 k = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
+                    const float mag = ONE ? cc.magnitude : s_ctr[i].w;
                     const float h = __builtin_fmaf(draw.z, k.z, __builtin_fmaf(draw.y, k.y, draw.x * k.x));
-                    const float q = h * h, e = dd * k.w;
-                    const float scale = q + __builtin_fabsf(e);
-                    maybe = maybe || !((q - e) < -1e-4f * scale) || !(scale < 1e30f);
+                    const float q = h * h;
+                    const float screen = __builtin_fmaf(kScreenMargin, __builtin_fmaf(dd, mag, q), __builtin_fmaf(-dd, k.w, q));
+                    maybe = maybe || (screen >= 0.0f);
                 }
 
                 f3 L = bg;
@@ -787,11 +896,27 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         else { func = reinterpret_cast<const void *>(camera_kernel<false, false>); hipLaunchKernelGGL((camera_kernel<false, false>), grid, dim3(kBlock), 0, stream, vc, b->cc, b->d_geom, b->d_sample_terms, argb_dev, rgba, b->d_rays); }
     } else {
         const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + kTileH - 1) / kTileH);
-        const bool single = vc.n_spheres <= static_cast<uint32_t>(kLdsSpheres);
-        if(exact && single) { func = reinterpret_cast<const void *>(path_kernel<true, true>); hipLaunchKernelGGL((path_kernel<true, true>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind, b->d_sample_terms, argb_dev, rgba, b->d_rays); }
-        else if(exact) { func = reinterpret_cast<const void *>(path_kernel<true, false>); hipLaunchKernelGGL((path_kernel<true, false>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind, b->d_sample_terms, argb_dev, rgba, b->d_rays); }
-        else if(single) { func = reinterpret_cast<const void *>(path_kernel<false, true>); hipLaunchKernelGGL((path_kernel<false, true>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind, b->d_sample_terms, argb_dev, rgba, b->d_rays); }
-        else { func = reinterpret_cast<const void *>(path_kernel<false, false>); hipLaunchKernelGGL((path_kernel<false, false>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind, b->d_sample_terms, argb_dev, rgba, b->d_rays); }
+        // List source.  Measured on MI355X the scalar-cache stream is as fast as or faster than LDS
+        // staging at every list length (no barrier, 8 waves/SIMD instead of 5), so it is the
+        // default; reserved[0] == 1 in the request selects LDS staging.
+        int list = kListScalar;
+        if(b->params.reserved[0] == 1u) list = vc.n_spheres <= static_cast<uint32_t>(kLdsSpheres) ? kListLdsOnce : kListLdsChunked;
+#define AEHIP_LAUNCH_PATH(E, L)                                                                                          \
+    do {                                                                                                               \
+        func = reinterpret_cast<const void *>(path_kernel<E, L>);                                                      \
+        hipLaunchKernelGGL((path_kernel<E, L>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind,    \
+                           b->d_sample_terms, argb_dev, rgba, b->d_rays);                                              \
+    } while(0)
+        if(exact) {
+            if(list == kListLdsOnce) AEHIP_LAUNCH_PATH(true, kListLdsOnce);
+            else if(list == kListLdsChunked) AEHIP_LAUNCH_PATH(true, kListLdsChunked);
+            else AEHIP_LAUNCH_PATH(true, kListScalar);
+        } else {
+            if(list == kListLdsOnce) AEHIP_LAUNCH_PATH(false, kListLdsOnce);
+            else if(list == kListLdsChunked) AEHIP_LAUNCH_PATH(false, kListLdsChunked);
+            else AEHIP_LAUNCH_PATH(false, kListScalar);
+        }
+#undef AEHIP_LAUNCH_PATH
     }
     AEHIP_CHECK(hipGetLastError());
 
@@ -891,8 +1016,17 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
     if(p.pass != AEHIP_PASS_PRIMARY && p.pass != AEHIP_PASS_PATH) return fail(AEHIP_E_INVALID, "unknown pass %u", p.pass);
     if(p.spp == 0 || p.max_depth == 0) return fail(AEHIP_E_INVALID, "spp and max_depth must be >= 1");
     if(scene->sphere_count == 0 || !scene->spheres) return fail(AEHIP_E_INVALID, "scene has no spheres");
+    // Coordinates must be finite and moderate: the kernels' screening tests assume that squared
+    // distances stay far from the fp32 overflow range.
+    auto moderate = [](float v) { return std::isfinite(v) && std::fabs(v) <= 1e12f; };
+    for(int k = 0; k < 3; k++) {
+        if(!moderate(scene->camera_pos[k])) return fail(AEHIP_E_INVALID, "camera position is not finite or beyond 1e12");
+    }
     for(uint32_t i = 0; i < scene->sphere_count; i++) {
-        if(scene->spheres[i].material > AEHIP_MAT_DIELECTRIC) return fail(AEHIP_E_INVALID, "sphere %u: unknown material %u", i, scene->spheres[i].material);
+        const aehip_sphere &sp = scene->spheres[i];
+        if(sp.material > AEHIP_MAT_DIELECTRIC) return fail(AEHIP_E_INVALID, "sphere %u: unknown material %u", i, sp.material);
+        if(!moderate(sp.center[0]) || !moderate(sp.center[1]) || !moderate(sp.center[2]) || !moderate(sp.radius))
+            return fail(AEHIP_E_INVALID, "sphere %u: centre or radius is not finite or beyond 1e12", i);
     }
 
     AEHIP_CHECK(hipSetDevice(b->device));
@@ -961,9 +1095,10 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
             // (src/shapes.cpp:15,18): oc = C - O, c = oc.oc - r*r
             const float ocx = geom[0].x - vc.cam[0], ocy = geom[0].y - vc.cam[1], ocz = geom[0].z - vc.cam[2];
             b->cc.oc[0] = ocx; b->cc.oc[1] = ocy; b->cc.oc[2] = ocz;
-            b->cc.c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - geom[0].w;
+            const float occ = (ocx * ocx + ocy * ocy) + ocz * ocz;
+            b->cc.c = occ - geom[0].w;
             b->cc.center[0] = geom[0].x; b->cc.center[1] = geom[0].y; b->cc.center[2] = geom[0].z;
-            b->cc.pad = 0.0f;
+            b->cc.magnitude = occ + geom[0].w;
         }
         hipError_t e = hipMemcpyAsync(b->d_geom, geom, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
         if(e == hipSuccess) e = hipMemcpyAsync(b->d_matl, matl, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);

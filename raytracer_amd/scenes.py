@@ -86,7 +86,22 @@ def showcase_scene() -> np.ndarray:
     return s
 
 
+def grazing_scene() -> np.ndarray:
+    """Adversarial for the intersection arithmetic: the camera (0,0,1) sits on the surface of a
+    huge diffuse ground sphere and next to large mirrors, so many rays start on, or graze, the
+    sphere they are tested against and discriminants hover around zero."""
+    s = np.zeros(6, dtype=SPHERE_DTYPE)
+    s["center"][0] = (0.0, -1000.0, 1.0); s["radius"][0] = 1000.0; s["material"][0] = MAT_LAMBERT; s["albedo"][0] = (0.7, 0.7, 0.7)
+    s["center"][1] = (0.0, 500.0, -900.0); s["radius"][1] = 700.0; s["material"][1] = MAT_METAL; s["albedo"][1] = (0.9, 0.9, 0.9)
+    s["center"][2] = (-3.0, 1.0, -4.0); s["radius"][2] = 1.0; s["material"][2] = MAT_METAL; s["albedo"][2] = (0.8, 0.8, 0.9); s["param"][2] = 0.05
+    s["center"][3] = (3.0, 1.0, -4.0); s["radius"][3] = 1.0; s["material"][3] = MAT_DIELECTRIC; s["albedo"][3] = (1, 1, 1); s["param"][3] = 1.5
+    s["center"][4] = (0.0, 0.25, -2.0); s["radius"][4] = 0.25; s["material"][4] = MAT_NORMAL; s["albedo"][4] = (1, 1, 1)
+    s["center"][5] = (0.0, 1.0, -6.0); s["radius"][5] = 1.0; s["material"][5] = MAT_LAMBERT; s["albedo"][5] = (0.9, 0.3, 0.3)
+    return s
+
+
 SCENES = {
+    "grazing": grazing_scene,
     "default": default_scene,
     "stress10k": stress_scene,
     "divergence": divergence_scene,

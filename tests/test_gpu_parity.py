@@ -52,7 +52,8 @@ def render_device(width, height, want_rgba=True, **kw):
     back = rt.HipRaytracer(None)
     try:
         assert back.setup(width, height, kw.pop("spp", 1), kw.pop("max_depth", 1), kw.pop("seed", 1), flags,
-                          kw.pop("pass_", rt.PASS_PATH), row_begin, row_count, kw.pop("spheres", None), **kw), back.last_error()
+                          kw.pop("pass_", rt.PASS_PATH), row_begin, row_count, kw.pop("spheres", None),
+                          kw.pop("list_source", 0), **kw), back.last_error()
         argb = torch.zeros((rows, width), dtype=torch.int32, device="cuda")
         rgba = torch.zeros((rows, width, 4), dtype=torch.float32, device="cuda") if want_rgba else None
         stream = torch.cuda.current_stream().cuda_stream
@@ -125,7 +126,10 @@ CASES = {
     "divergence_depth50": dict(size=(96, 64), spp=4, max_depth=50, seed=7, jitter=True, spheres="divergence"),
     "portrait_showcase": dict(size=(36, 100), spp=2, max_depth=5, seed=5, jitter=True, spheres="showcase"),
     "stress_multichunk": dict(size=(48, 28), spp=1, max_depth=3, seed=42, jitter=True, spheres="stress3000"),
+    "grazing_depth20": dict(size=(128, 96), spp=8, max_depth=20, seed=13, jitter=True, spheres="grazing"),
+    "stress_depth6": dict(size=(64, 40), spp=3, max_depth=6, seed=4, jitter=True, spheres="stress3000"),
 }
+LIST_SOURCES = {"scalar": 0, "lds": 1}
 
 
 def case_spheres(name):
@@ -136,15 +140,16 @@ def case_spheres(name):
     return scenes.SCENES[name]()
 
 
+@pytest.mark.parametrize("source", list(LIST_SOURCES))
 @pytest.mark.parametrize("name", list(CASES))
-def test_path_pass_exact_is_bit_identical_to_oracle(name):
+def test_path_pass_exact_is_bit_identical_to_oracle(name, source):
     c = CASES[name]
     w, h = c["size"]
     sph = case_spheres(c["spheres"])
     want_argb, want_rgba, want_rays, _ = oracle.trace_paths(w, h, spp=c["spp"], max_depth=c["max_depth"], seed=c["seed"],
                                                             jitter=c["jitter"], spheres=sph, threads=8, want_rgba=True)
     got_argb, got_rgba, st = render_device(w, h, spp=c["spp"], max_depth=c["max_depth"], seed=c["seed"],
-                                           jitter=c["jitter"], spheres=sph, count_rays=True)
+                                           jitter=c["jitter"], spheres=sph, count_rays=True, list_source=LIST_SOURCES[source])
     np.testing.assert_array_equal(got_rgba.view(np.uint32), want_rgba.view(np.uint32))
     np.testing.assert_array_equal(got_argb, want_argb)
     assert st.rays == want_rays
