@@ -3,17 +3,26 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode fast|exact] [--spp S]
 
-One step = one full frame: every rank renders its row band with the HIP path kernel (scene and
-framebuffer resident in HBM), then the bands are gathered to rank 0 (RCCL) when N > 1.  Total
-work per step is fixed (one 4K frame), so scaling over N is "strong".  Rank 0 prints ONE JSON
-line.  With N > 1 the driver launches this file under torch.distributed.run, one rank per GPU.
+One step = one full frame: every rank renders its row band with the HIP camera/path kernel
+(scene and framebuffer resident in HBM), then the bands are gathered to rank 0 (RCCL) when
+N > 1.  Total work per step is fixed (one 4K frame), so scaling over N is "strong".  Rank 0
+prints ONE JSON line.  With N > 1 the driver launches this file under torch.distributed.run,
+one rank per GPU.
+
+Arithmetic: `value` is measured with the fast build (explicit FMA, v_rcp/v_rsq/v_sqrt), whose
+1024-spp image is held to a PSNR bound against the bit-exact build and the CPU oracle
+(tests/test_gpu_parity.py).  The same frame rendered by the exact build (bit-identical to the
+oracle, and to the reference wherever the reference defines the result) is timed in the same
+run and reported under "exact".  --mode exact swaps the two.
 
 The line also carries
-  roofline      the path kernel's algorithmic FP32 flops / its mean launch time (HIP events on
-                the launch stream, inside the timed region) against the FP32 vector peak, and
+  roofline      the kernel's algorithmic FP32 flops / its mean launch time (HIP events on the
+                launch stream, inside the timed region) against the FP32 vector peak,
   cpu_baseline  the CPU oracle (a port of the reference's pixel kernel extended with sampling)
                 timed on this host's cores on a bounded sample of the same frame, plus the real
-                reference binary's 1-sample figure where oracle/_ref was shipped.
+                reference binary's 1-sample figure where oracle/_ref was shipped,
+  aux           (N=1, unless --no-aux) the reference-pinned primary pass at 4K against HBM store
+                bandwidth, and the 2,000-sphere brute-force scene against the FP32 vector peak.
 """
 import argparse
 import json
@@ -28,6 +37,8 @@ sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT = 3840, 2160
 FP32_VECTOR_PEAK_TFLOPS = 157.3     # MI355X datasheet FP32 vector peak (256 CU x 256 flop/clk x 2.4 GHz)
+FP32_FMA_MEASURED_TFLOPS = 108.0    # what back-to-back v_fma_f32 sustains on this part (tools/valu_peak.hip)
+HBM_PEAK_GBS = 8000.0
 
 # Algorithmic FP32 flops of the default-scene path pass, counted on the reference's formulas with
 # div and sqrt = 1 flop each and integer / compare / convert = 0:
@@ -43,12 +54,14 @@ HIT_FRACTION_16_9 = 1832112.0 / 8294400.0   # sphere pixels in the reference's o
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["fast", "exact"], default="fast")
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux", action="store_true")
+    ap.add_argument("--no-second-mode", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
@@ -59,9 +72,9 @@ def cpu_baseline(target_seconds: float):
 
     threads = max(1, min(16, os.cpu_count() or 1))
     # calibrate on a thin band, then size the sample count for about target_seconds
-    _, _, _, ms = oracle.trace_paths(WIDTH, HEIGHT, spp=1, max_depth=8, seed=1, jitter=True, row_begin=1000,
-                                     row_count=64, threads=threads)
-    per_spp_s = ms * 1e-3 * HEIGHT / 64.0
+    _, _, _, ms = oracle.trace_paths(WIDTH, HEIGHT, spp=4, max_depth=8, seed=1, jitter=True, row_begin=800,
+                                     row_count=512, threads=threads)
+    per_spp_s = ms * 1e-3 * HEIGHT / 512.0 / 4.0
     spp = max(1, min(1024, int(target_seconds / max(per_spp_s, 1e-6))))
     _, _, rays, ms = oracle.trace_paths(WIDTH, HEIGHT, spp=spp, max_depth=8, seed=1, jitter=True, threads=threads)
     out = {
@@ -90,6 +103,10 @@ def cpu_baseline(target_seconds: float):
     return out
 
 
+def frame_flops(paths, pixels):
+    return paths * (HIT_FRACTION_16_9 * FLOP_SAMPLE_HIT + (1 - HIT_FRACTION_16_9) * FLOP_SAMPLE_MISS) + pixels * FLOP_PIXEL
+
+
 def main():
     args = parse()
     import torch
@@ -101,9 +118,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world == 1 and args.gpus > 1:
+        sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -112,49 +128,48 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     gather = BandGather(WIDTH, HEIGHT, device)
-    flags = rt.FLAG_JITTER | (rt.FLAG_FAST if args.mode == "fast" else 0)
-    back = rt.HipRaytracer(None, device=local_rank)
-    if not back.setup(WIDTH, HEIGHT, spp=args.spp, max_depth=args.depth, seed=1, flags=flags, pass_=rt.PASS_PATH,
-                      row_begin=gather.row_begin, row_count=gather.rows):
-        sys.exit("setup failed: " + back.last_error())
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
-        back.trace_device(gather.local.data_ptr(), None, stream)
-        return gather.gather()
+    def timed_run(mode, steps, warmup):
+        """K steps of render-band + gather; returns (elapsed_s max over ranks, kernel_s max over ranks, stats)."""
+        flags = rt.FLAG_JITTER | (rt.FLAG_FAST if mode == "fast" else 0)
+        back = rt.HipRaytracer(None, device=local_rank)
+        if not back.setup(WIDTH, HEIGHT, spp=args.spp, max_depth=args.depth, seed=1, flags=flags, pass_=rt.PASS_PATH,
+                          row_begin=gather.row_begin, row_count=gather.rows):
+            sys.exit("setup failed: " + back.last_error())
+        for _ in range(warmup):
+            back.trace_device(gather.local.data_ptr(), None, stream)
+            gather.gather()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ev[i][0].record()
+            back.trace_device(gather.local.data_ptr(), None, stream)
+            ev[i][1].record()
+            gather.gather()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+        t = torch.tensor([elapsed, kernel_ms * 1e-3], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        st = back.stats()
+        back.close()
+        return float(t[0]), float(t[1]), st
 
-    for _ in range(args.warmup):
-        step()
-
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        back.trace_device(gather.local.data_ptr(), None, stream)
-        ev[i][1].record()
-        image = gather.gather()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    t = torch.tensor([elapsed, kernel_ms * 1e-3], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, kernel_s = float(t[0]), float(t[1])
+    other = "exact" if args.mode == "fast" else "fast"
+    elapsed, kernel_s, st = timed_run(args.mode, args.steps, args.warmup)
+    second = None if args.no_second_mode else timed_run(other, max(2, args.steps // 2), 1)
 
     if rank == 0:
-        st = back.stats()
         paths_total = WIDTH * HEIGHT * args.spp
-        ms_per_step = elapsed / args.steps * 1e3
-        # flops of the band the slowest rank renders ~ total / world (bands are equal at 1,2,4,8)
-        band_paths = paths_total / world
-        band_pixels = WIDTH * HEIGHT / world
-        flops = band_paths * (HIT_FRACTION_16_9 * FLOP_SAMPLE_HIT + (1 - HIT_FRACTION_16_9) * FLOP_SAMPLE_MISS) + band_pixels * FLOP_PIXEL
+        # the slowest rank renders 1/world of the frame (bands are equal at 1,2,4,8 GPUs)
+        flops = frame_flops(paths_total / world, WIDTH * HEIGHT / world)
         achieved = flops / kernel_s / 1e12
         line = {
             "metric": "Mpaths/sec at 3840x2160",
@@ -163,7 +178,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -184,19 +199,85 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
                 "traffic": None,
-                "kernel": "path_kernel",
+                "kernel": "camera_kernel",
                 "flop_per_launch": flops,
+                # algorithmic flops (the reference's formulas) over the rate back-to-back v_fma_f32
+                # sustains; can exceed 1 because the fast build executes fewer operations than the
+                # reference's formulas count (no normalisation of rays that miss, folded constants)
+                "algorithmic_vs_measured_fma_rate": achieved / FP32_FMA_MEASURED_TFLOPS,
                 "vgprs": st.vgprs,
                 "lds_bytes": st.lds_bytes,
             },
         }
+        if second is not None:
+            e2, k2, st2 = second
+            steps2 = max(2, args.steps // 2)
+            a2 = flops / k2 / 1e12
+            line[other] = {
+                "value": paths_total / (e2 / steps2) / 1e6, "unit": "Mpaths/s", "ms_per_step": e2 / steps2 * 1e3,
+                "kernel_ms": k2 * 1e3, "steps": steps2,
+                "roofline": {"bound": "valu_fp32", "achieved": a2, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": a2 / FP32_VECTOR_PEAK_TFLOPS, "vgprs": st2.vgprs},
+            }
+        if world == 1 and not args.no_aux:
+            line["aux"] = aux_measurements(rt, torch, stream)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)
 
-    back.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def aux_measurements(rt, torch, stream):
+    """Secondary kernels on one GPU, each against the roofline that bounds it."""
+    from raytracer_amd import scenes
+
+    out = {}
+    # the reference-pinned pass: 1 centred ray per pixel; HBM-store / launch bound (4 B per pixel)
+    back = rt.HipRaytracer(None)
+    back.setup(WIDTH, HEIGHT, pass_=rt.PASS_PRIMARY)
+    argb = torch.zeros((HEIGHT, WIDTH), dtype=torch.int32, device="cuda")
+    reps = 50
+    for _ in range(5):
+        back.trace_device(argb.data_ptr(), None, stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        back.trace_device(argb.data_ptr(), None, stream)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    back.close()
+    nbytes = WIDTH * HEIGHT * 4
+    out["primary_pass_4k_exact"] = {
+        "ms_per_frame": ms, "mpaths_per_s": WIDTH * HEIGHT / ms / 1e3,
+        "roofline": {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": nbytes,
+                     "note": "33 MB store per launch; launches back to back, so the figure includes launch gaps"},
+    }
+    # brute-force list: 2,000 spheres, primary rays only, 18 flop per ray-sphere test
+    sph = scenes.stress_scene(2000, 42)
+    for mode in ("fast", "exact"):
+        back = rt.HipRaytracer(None)
+        flags = rt.FLAG_JITTER | rt.FLAG_COUNT_RAYS | (rt.FLAG_FAST if mode == "fast" else 0)
+        back.setup(1920, 1080, spp=4, max_depth=1, seed=1, flags=flags, pass_=rt.PASS_PATH, spheres=sph)
+        img = torch.zeros((1080, 1920), dtype=torch.int32, device="cuda")
+        best = None
+        for _ in range(3):
+            back.trace_device(img.data_ptr(), None, stream)
+            torch.cuda.synchronize()
+            s = back.stats()
+            best = s.kernel_ms if best is None else min(best, s.kernel_ms)
+        tests = s.rays * len(sph)
+        tf = tests * 18.0 / (best * 1e-3) / 1e12
+        out[f"stress2k_1080p_4spp_depth1_{mode}"] = {
+            "kernel_ms": best, "sphere_tests_per_s": tests / (best * 1e-3), "mpaths_per_s": s.paths / best / 1e3,
+            "roofline": {"bound": "valu_fp32", "achieved": tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / FP32_VECTOR_PEAK_TFLOPS},
+        }
+        back.close()
+    return out
 
 
 if __name__ == "__main__":

@@ -43,7 +43,11 @@ enum {
                                     (src/software_raytracer.cpp:218)                         */
     AEHIP_FLAG_FAST       = 2u,  /* fused multiply-add and hardware reciprocal / rsqrt; off =
                                     IEEE fp32 in the reference's operation order             */
-    AEHIP_FLAG_COUNT_RAYS = 4u   /* count ray segments on the device (aehip_stats.rays)      */
+    AEHIP_FLAG_COUNT_RAYS = 4u,  /* count ray segments and lane slots on the device
+                                    (aehip_stats.rays, aehip_stats.lane_slots)               */
+    AEHIP_FLAG_NO_REGEN   = 8u   /* measurement aid: a lane whose path ended waits until every
+                                    lane of its wave is done before starting its next sample
+                                    (the image is unchanged; only lane utilisation differs)  */
 };
 
 enum {
@@ -83,7 +87,10 @@ typedef struct aehip_params {
     uint32_t seed;
     uint32_t flags;                 /* AEHIP_FLAG_* */
     uint32_t pass;                  /* AEHIP_PASS_* */
-    uint32_t reserved[3];
+    uint32_t list_source;           /* where the path pass reads the shape list from: 0 = library's
+                                       choice, 1 = staged in LDS per workgroup, 2 = streamed through
+                                       the scalar cache.  Results are identical; only speed differs. */
+    uint32_t reserved[2];
 } aehip_params;
 
 typedef struct aehip_stats {
@@ -91,6 +98,9 @@ typedef struct aehip_stats {
     float    copy_ms;       /* device->host copy of the last aehip_backend_trace           */
     uint64_t rays;          /* ray segments (only with AEHIP_FLAG_COUNT_RAYS)              */
     uint64_t paths;         /* width * rows * spp of the last trace                        */
+    uint64_t lane_slots;    /* 64 x (segment iterations executed by all waves): rays / lane_slots
+                               is the fraction of lanes doing useful work in the bounce loop
+                               (only with AEHIP_FLAG_COUNT_RAYS)                            */
     uint32_t vgprs, sgprs, lds_bytes, reserved;   /* resource use of the kernel last launched */
 } aehip_stats;
 

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhip_raytracer.so")
 
 MAT_NORMAL, MAT_LAMBERT, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2, 3
-FLAG_JITTER, FLAG_FAST, FLAG_COUNT_RAYS = 1, 2, 4
+FLAG_JITTER, FLAG_FAST, FLAG_COUNT_RAYS, FLAG_NO_REGEN = 1, 2, 4, 8
 PASS_PRIMARY, PASS_PATH = 0, 1
 
 SPHERE_DTYPE = np.dtype(
@@ -53,7 +53,8 @@ class AehipParams(ctypes.Structure):
         ("seed", ctypes.c_uint32),
         ("flags", ctypes.c_uint32),
         ("pass_", ctypes.c_uint32),
-        ("reserved", ctypes.c_uint32 * 3),
+        ("list_source", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32 * 2),
     ]
 
 
@@ -63,6 +64,7 @@ class AehipStats(ctypes.Structure):
         ("copy_ms", ctypes.c_float),
         ("rays", ctypes.c_uint64),
         ("paths", ctypes.c_uint64),
+        ("lane_slots", ctypes.c_uint64),
         ("vgprs", ctypes.c_uint32),
         ("sgprs", ctypes.c_uint32),
         ("lds_bytes", ctypes.c_uint32),
@@ -179,7 +181,7 @@ class HipRaytracer:
               row_count=0, spheres=None, list_source=0, **scene_kw) -> bool:
         sc, keep = make_scene(spheres, **scene_kw)
         p = AehipParams(width, height, row_begin, row_count, spp, max_depth, seed, flags, pass_)
-        p.reserved[0] = list_source      # 0 = library's choice, 1 = LDS staging, 2 = scalar-cache stream
+        p.list_source = list_source      # 0 = library's choice, 1 = LDS staging, 2 = scalar-cache stream
         rc = self._lib.aehip_backend_setup(self._h, ctypes.byref(sc), ctypes.byref(p))
         del keep
         self.params = p
@@ -214,13 +216,14 @@ class HipRaytracer:
 
 
 def render(width, height, spp=1, max_depth=1, seed=1, jitter=False, fast=False, count_rays=False,
-           pass_=PASS_PATH, row_begin=0, row_count=0, spheres=None, device=0, **scene_kw):
+           pass_=PASS_PATH, row_begin=0, row_count=0, spheres=None, device=0, no_regen=False, **scene_kw):
     """One-shot helper: render a band into host memory through setup()/trace().
     Returns (argb uint32 [rows, width], stats)."""
     rows = row_count if row_count else height - row_begin
     fb = np.zeros((rows, width), dtype=np.uint32)
     rt = HipRaytracer(fb, device)
-    flags = (FLAG_JITTER if jitter else 0) | (FLAG_FAST if fast else 0) | (FLAG_COUNT_RAYS if count_rays else 0)
+    flags = (FLAG_JITTER if jitter else 0) | (FLAG_FAST if fast else 0) | (FLAG_COUNT_RAYS if count_rays else 0) \
+        | (FLAG_NO_REGEN if no_regen else 0)
     try:
         if not rt.setup(width, height, spp, max_depth, seed, flags, pass_, row_begin, row_count, spheres, **scene_kw):
             raise HipRaytracerError("setup failed: " + rt.last_error())

@@ -551,7 +551,10 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
     f3 sum = {0.0f, 0.0f, 0.0f};
     uint32_t sample = 0;
     uint32_t nrays = 0;
-    bool alive = valid;
+    uint32_t iterations = 0;        // segment iterations this wave executed (same value in every lane)
+    bool alive = valid;             // the pixel still has samples to finish
+    bool tracing = valid;           // the lane is following a path right now
+    const bool regenerate = !(vc.flags & AEHIP_FLAG_NO_REGEN);
     path_state ps;
     ps.o = ps.d = ps.thr = f3{0.0f, 0.0f, 0.0f};
     ps.rng = 0;
@@ -565,6 +568,15 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
         } else {
             if(!__syncthreads_or(alive)) break;
         }
+        // without regeneration a finished lane idles until its whole wave has finished, then
+        // the wave starts the next sample together
+        if(!regenerate && !__any(tracing)) {
+            if(alive) {
+                start_path<EXACT>(vc, pix_term, sample_terms, x, y, sample, ps);
+                tracing = true;
+            }
+        }
+        iterations++;
 
         const float a = dot3<EXACT>(ps.d, ps.d);
         const float a4 = 4.0f * a;
@@ -573,20 +585,20 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
         int hit = -1;
 
         if constexpr(LIST == kListLdsOnce) {
-            if(alive) intersect_chunk<EXACT>(s_geom, vc.n_spheres, 0, ps.o, ps.d, a2, a4, closest, hit);
+            if(tracing) intersect_chunk<EXACT>(s_geom, vc.n_spheres, 0, ps.o, ps.d, a2, a4, closest, hit);
         } else if constexpr(LIST == kListScalar) {
-            if(alive) intersect_chunk<EXACT>(geom, vc.n_spheres, 0, ps.o, ps.d, a2, a4, closest, hit);
+            if(tracing) intersect_chunk<EXACT>(geom, vc.n_spheres, 0, ps.o, ps.d, a2, a4, closest, hit);
         } else {
             for(uint32_t base = 0; base < vc.n_spheres; base += kLdsSpheres) {
                 const uint32_t count = min(static_cast<uint32_t>(kLdsSpheres), vc.n_spheres - base);
                 __syncthreads();
                 for(uint32_t i = tid; i < count; i += kBlock) s_geom[i] = geom[base + i];
                 __syncthreads();
-                if(alive) intersect_chunk<EXACT>(s_geom, count, base, ps.o, ps.d, a2, a4, closest, hit);
+                if(tracing) intersect_chunk<EXACT>(s_geom, count, base, ps.o, ps.d, a2, a4, closest, hit);
             }
         }
 
-        if(alive) {
+        if(tracing) {
             nrays++;
             f3 L;
             if(shade_segment<EXACT>(vc, y, hit, closest, geom, matl, kind, ps, L)) {
@@ -594,8 +606,14 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
                 sum.y += L.y;
                 sum.z += L.z;
                 sample++;
-                if(sample < vc.spp) start_path<EXACT>(vc, pix_term, sample_terms, x, y, sample, ps);
-                else alive = false;
+                if(sample >= vc.spp) {
+                    alive = false;
+                    tracing = false;
+                } else if(regenerate) {
+                    start_path<EXACT>(vc, pix_term, sample_terms, x, y, sample, ps);
+                } else {
+                    tracing = false;
+                }
             }
         }
     }
@@ -611,11 +629,14 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
     }
 
     if(vc.flags & AEHIP_FLAG_COUNT_RAYS) {
-        // wave-level sum, one atomic per wave
+        // wave-level sum, one atomic per wave and counter
         uint32_t v = nrays;
 #pragma unroll
         for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if((tid & 63u) == 0) atomicAdd(ray_counter, static_cast<unsigned long long>(v));
+        if((tid & 63u) == 0) {
+            atomicAdd(ray_counter, static_cast<unsigned long long>(v));
+            atomicAdd(ray_counter + 1, 64ull * iterations);
+        }
     }
 }
 
@@ -809,9 +830,13 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
 
     if(vc.flags & AEHIP_FLAG_COUNT_RAYS) {
         uint32_t v = valid ? vc.spp : 0u;
+        const bool wave_has_work = __any(valid);
 #pragma unroll
         for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if((tid & 63u) == 0) atomicAdd(ray_counter, static_cast<unsigned long long>(v));
+        if((tid & 63u) == 0) {
+            atomicAdd(ray_counter, static_cast<unsigned long long>(v));
+            atomicAdd(ray_counter + 1, wave_has_work ? 64ull * vc.spp : 0ull);
+        }
     }
 }
 
@@ -866,6 +891,7 @@ struct aehip_backend {
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_copy = nullptr;
     bool timed_on_own_stream = false;
+    const void *attr_func = nullptr;         // kernel whose resource figures are in stats
     aehip_stats stats{};
 };
 
@@ -877,7 +903,7 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
     float4 *rgba = reinterpret_cast<float4 *>(rgba_dev);
     const void *func = nullptr;
 
-    if(vc.flags & AEHIP_FLAG_COUNT_RAYS) AEHIP_CHECK(hipMemsetAsync(b->d_rays, 0, sizeof(unsigned long long), stream));
+    if(vc.flags & AEHIP_FLAG_COUNT_RAYS) AEHIP_CHECK(hipMemsetAsync(b->d_rays, 0, 2 * sizeof(unsigned long long), stream));
 
     if(b->params.pass == AEHIP_PASS_PRIMARY) {
         const bool vec4 = (vc.width % 4u) == 0 && (reinterpret_cast<uintptr_t>(argb_dev) % 16u) == 0;
@@ -898,9 +924,9 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + kTileH - 1) / kTileH);
         // List source.  Measured on MI355X the scalar-cache stream is as fast as or faster than LDS
         // staging at every list length (no barrier, 8 waves/SIMD instead of 5), so it is the
-        // default; reserved[0] == 1 in the request selects LDS staging.
+        // default; list_source == 1 in the request selects LDS staging.
         int list = kListScalar;
-        if(b->params.reserved[0] == 1u) list = vc.n_spheres <= static_cast<uint32_t>(kLdsSpheres) ? kListLdsOnce : kListLdsChunked;
+        if(b->params.list_source == 1u) list = vc.n_spheres <= static_cast<uint32_t>(kLdsSpheres) ? kListLdsOnce : kListLdsChunked;
 #define AEHIP_LAUNCH_PATH(E, L)                                                                                          \
     do {                                                                                                               \
         func = reinterpret_cast<const void *>(path_kernel<E, L>);                                                      \
@@ -920,10 +946,14 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
     }
     AEHIP_CHECK(hipGetLastError());
 
-    hipFuncAttributes attr;
-    if(hipFuncGetAttributes(&attr, func) == hipSuccess) {
-        b->stats.vgprs = static_cast<uint32_t>(attr.numRegs);
-        b->stats.lds_bytes = static_cast<uint32_t>(attr.sharedSizeBytes);
+    // resource figures of the kernel just launched; queried once per kernel and backend, not per launch
+    if(func != b->attr_func) {
+        hipFuncAttributes attr;
+        if(hipFuncGetAttributes(&attr, func) == hipSuccess) {
+            b->stats.vgprs = static_cast<uint32_t>(attr.numRegs);
+            b->stats.lds_bytes = static_cast<uint32_t>(attr.sharedSizeBytes);
+        }
+        b->attr_func = func;
     }
     b->stats.paths = static_cast<uint64_t>(vc.width) * vc.row_count * (b->params.pass == AEHIP_PASS_PRIMARY ? 1u : vc.spp);
     return AEHIP_OK;
@@ -974,7 +1004,7 @@ int aehip_backend_create(int device, uint32_t *framebuffer, aehip_backend **out)
     if(e == hipSuccess) e = hipEventCreate(&b->ev_begin);
     if(e == hipSuccess) e = hipEventCreate(&b->ev_end);
     if(e == hipSuccess) e = hipEventCreate(&b->ev_copy);
-    if(e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_rays), sizeof(unsigned long long));
+    if(e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_rays), 2 * sizeof(unsigned long long));
     if(e != hipSuccess) {
         const int rc = fail(AEHIP_E_HIP, "backend create on device %d: %s", device, hipGetErrorString(e));
         aehip_backend_destroy(b);
@@ -1191,11 +1221,13 @@ int aehip_backend_stats(aehip_backend *b, aehip_stats *out) {
     AEHIP_CHECK(hipEventElapsedTime(&ms, b->ev_begin, b->ev_end));
     b->stats.kernel_ms = ms;
     if(b->vc.flags & AEHIP_FLAG_COUNT_RAYS) {
-        unsigned long long rays = 0;
-        AEHIP_CHECK(hipMemcpy(&rays, b->d_rays, sizeof(rays), hipMemcpyDeviceToHost));
-        b->stats.rays = rays;
+        unsigned long long counters[2] = {0, 0};
+        AEHIP_CHECK(hipMemcpy(counters, b->d_rays, sizeof(counters), hipMemcpyDeviceToHost));
+        b->stats.rays = counters[0];
+        b->stats.lane_slots = counters[1];
     } else {
         b->stats.rays = 0;
+        b->stats.lane_slots = 0;
     }
     *out = b->stats;
     return AEHIP_OK;

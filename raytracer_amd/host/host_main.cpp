@@ -41,10 +41,11 @@ int main(int argc, char *argv[]) {
                 } else if(options.enabled("stats")) {
                     const aehip_stats st = backend.stats();
                     std::fprintf(stderr,
-                                 "{\"width\": %u, \"height\": %u, \"paths\": %llu, \"rays\": %llu, \"kernel_ms\": %.4f, "
+                                 "{\"width\": %u, \"height\": %u, \"paths\": %llu, \"rays\": %llu, \"lane_slots\": %llu, \"kernel_ms\": %.4f, "
                                  "\"copy_ms\": %.4f, \"mpaths_per_s\": %.1f, \"vgprs\": %u, \"lds_bytes\": %u}\n",
                                  width, height, static_cast<unsigned long long>(st.paths),
-                                 static_cast<unsigned long long>(st.rays), st.kernel_ms, st.copy_ms,
+                                 static_cast<unsigned long long>(st.rays),
+                                 static_cast<unsigned long long>(st.lane_slots), st.kernel_ms, st.copy_ms,
                                  st.kernel_ms > 0 ? static_cast<double>(st.paths) / (st.kernel_ms * 1e3) : 0.0, st.vgprs,
                                  st.lds_bytes);
                 }

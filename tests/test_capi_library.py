@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(raytracer_amd.AehipParams) == 48
     assert ctypes.sizeof(raytracer_amd.AehipScene) == 64
-    assert ctypes.sizeof(raytracer_amd.AehipStats) == 40
+    assert ctypes.sizeof(raytracer_amd.AehipStats) == 48
     assert raytracer_amd.SPHERE_DTYPE.itemsize == 48
 
 

@@ -246,3 +246,19 @@ def test_tame_division_and_sqrt_equal_the_ieee_operators():
     assert res.returncode == 0, report
     assert report["div_mismatch"] == 0 and report["div_shared_rcp_mismatch"] == 0 and report["sqrt_mismatch"] == 0
     assert report["pairs_per_test"] >= 2 ** 31
+
+
+# ------------------------------------------------------------------ divergence handling
+
+def test_regeneration_keeps_lanes_busy_and_never_changes_the_image():
+    """Path regeneration is scheduling only: the image and the ray count are the same with it
+    switched off, while the fraction of lanes doing useful work in the bounce loop drops."""
+    sph = scenes.divergence_scene()
+    kw = dict(spp=8, max_depth=50, seed=7, jitter=True, spheres=sph, count_rays=True)
+    on, st_on = rt.render(192, 108, **kw)
+    off, st_off = rt.render(192, 108, no_regen=True, **kw)
+    np.testing.assert_array_equal(on, off)
+    assert st_on.rays == st_off.rays
+    util_on, util_off = st_on.rays / st_on.lane_slots, st_off.rays / st_off.lane_slots
+    assert 0.0 < util_off < util_on <= 1.0
+    assert util_on >= 1.25 * util_off

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--case", nargs="*", default=list(CASES))
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--list", type=int, default=0, help="shape-list source: 0 auto, 1 LDS, 2 scalar cache")
+    ap.add_argument("--no-regen", action="store_true", help="disable path regeneration (lane utilisation study)")
     args = ap.parse_args()
     import torch
 
@@ -43,7 +44,8 @@ def main():
         w, h, spp, depth, make = CASES[name]
         sph = make()
         back = rt.HipRaytracer(None)
-        flags = rt.FLAG_JITTER | rt.FLAG_COUNT_RAYS | (rt.FLAG_FAST if args.mode == "fast" else 0)
+        flags = rt.FLAG_JITTER | rt.FLAG_COUNT_RAYS | (rt.FLAG_FAST if args.mode == "fast" else 0) \
+            | (rt.FLAG_NO_REGEN if args.no_regen else 0)
         assert back.setup(w, h, spp=spp, max_depth=depth, seed=1, flags=flags, pass_=rt.PASS_PATH, spheres=sph, list_source=args.list), back.last_error()
         argb = torch.zeros((h, w), dtype=torch.int32, device="cuda")
         best = None
@@ -52,11 +54,12 @@ def main():
             torch.cuda.synchronize()
             st = back.stats()
             if best is None or st.kernel_ms < best[0]:
-                best = (st.kernel_ms, st.rays, st.paths, st.vgprs, st.lds_bytes)
-        ms, rays, paths, vgprs, lds = best
+                best = (st.kernel_ms, st.rays, st.paths, st.vgprs, st.lds_bytes, st.lane_slots)
+        ms, rays, paths, vgprs, lds, slots = best
         flop = rays * len(sph) * 18.0
         print(json.dumps({
-            "case": name, "arithmetic": args.mode, "list": args.list, "spheres": int(len(sph)), "kernel_ms": ms,
+            "case": name, "arithmetic": args.mode, "list": args.list, "regeneration": not args.no_regen,
+            "lane_utilisation": rays / slots if slots else None, "spheres": int(len(sph)), "kernel_ms": ms,
             "mpaths_per_s": paths / ms / 1e3, "grays_per_s": rays / ms / 1e6, "rays_per_path": rays / paths,
             "sphere_tests_per_s": rays * len(sph) / (ms * 1e-3),
             "intersect_tflops": flop / (ms * 1e-3) / 1e12, "vgprs": vgprs, "lds_bytes": lds,
