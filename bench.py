@@ -146,10 +146,12 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            ev[i][0].record()
-            back.trace_device(gather.local.data_ptr(), None, stream)
+            band = gather.begin(i)              # alternating band buffers: the gather of frame i
+            ev[i][0].record()                   # overlaps the render of frame i+1
+            back.trace_device(band.data_ptr(), None, stream)
             ev[i][1].record()
-            gather.gather()
+            gather.submit(i)
+        gather.finish()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -59,3 +59,33 @@ def test_gather_of_bands_rebuilds_reference_image(tmp_path, world, size):
     image = np.load(out)
     want = next(e["sha256"] for e in META["images"] if (e["width"], e["height"]) == (width, height))
     assert hashlib.sha256(image.tobytes()).hexdigest() == want
+
+
+def _worker_overlapped(rank, world, port, width, height, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = BandGather(width, height, torch.device("cpu"))
+        band = torch.from_numpy(oracle.trace_primary(width, height, row_begin=g.row_begin, row_count=g.rows).view(np.int32))
+        frames = 5
+        for i in range(frames):
+            buf = g.begin(i)
+            # frames 0..3 carry a marker, the last frame carries the real band
+            buf[: g.rows].copy_(band if i == frames - 1 else torch.full_like(band, i + 1))
+            g.submit(i)
+        image = g.finish()
+        if rank == 0:
+            np.save(out_path, image.numpy().view(np.uint32))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,size", [(2, (128, 72)), (4, (512, 64))])
+def test_overlapped_gather_delivers_the_last_frame(tmp_path, world, size):
+    """The double-buffered begin/submit/finish form used by bench.py."""
+    width, height = size
+    out = str(tmp_path / "image.npy")
+    mp.spawn(_worker_overlapped, args=(world, free_port(), width, height, out), nprocs=world, join=True)
+    image = np.load(out)
+    want = next(e["sha256"] for e in META["images"] if (e["width"], e["height"]) == (width, height))
+    assert hashlib.sha256(image.tobytes()).hexdigest() == want
