@@ -200,7 +200,10 @@ def main():
                 "peak": FP32_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
-                "traffic": None,
+                # HBM bytes per launch from the PMC passes of the same command (profiles/r01_*_bench_*.txt:
+                # WRITE_SIZE 32400 KiB = 4 B x 8,294,400 px exactly, FETCH_SIZE ~0.1 MB after the gfx950 x2
+                # correction); a band of 1/N of the frame writes 1/N of it
+                "traffic": (33_177_600 + 114_000) // world,
                 "kernel": "camera_kernel",
                 "flop_per_launch": flops,
                 # algorithmic flops (the reference's formulas) over the rate back-to-back v_fma_f32

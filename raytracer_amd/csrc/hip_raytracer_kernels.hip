@@ -219,41 +219,69 @@ __device__ __forceinline__ f3 unit_vector(uint32_t bits) {
 }
 
 // ------------------------------------------------------------------------------------------
+// constants of sphere 0 as seen from the camera (primary pass and single-sphere camera pass)
+// ------------------------------------------------------------------------------------------
+
+struct camera_consts {       // travels as a kernel argument (SGPRs)
+    float oc[3];             // centre - camera (src/shapes.cpp:15)
+    float c;                 // oc.oc - r*r     (src/shapes.cpp:18)
+    float center[3];
+    float magnitude;         // oc.oc + r*r: size of the terms behind c, for the screening margin
+};
+
+// Relative margin of the exact build's conservative miss tests (see screen_sphere below).
+constexpr float kScreenMargin = 3e-5f;
+
+// ------------------------------------------------------------------------------------------
 // primary pass: the reference's pixel kernel, 4 horizontally adjacent pixels per lane so the
 // packed image leaves as one 16-byte store per lane (1 KiB per wave instruction)
 // ------------------------------------------------------------------------------------------
 
 template <bool EXACT>
-__device__ __forceinline__ uint32_t primary_pixel(const view_consts &vc, const float4 sphere, uint32_t x, uint32_t y,
-                                                  const f3 bg, f3 &rgb_out) {
+__device__ __forceinline__ f3 primary_pixel(const view_consts &vc, const camera_consts &cc, uint32_t x, uint32_t y, const f3 bg) {
     const f3 cam = {vc.cam[0], vc.cam[1], vc.cam[2]};
-    const f3 d = primary_direction<EXACT>(vc, static_cast<float>(x) + 0.5f, static_cast<float>(y) + 0.5f);
+    const f3 oc = {cc.oc[0], cc.oc[1], cc.oc[2]};
+    const f3 ctr = {cc.center[0], cc.center[1], cc.center[2]};
+    // src/software_raytracer.cpp:218-221: viewport point of the pixel centre minus the camera
+    const float uvx = rt_fma<EXACT>(static_cast<float>(x) + 0.5f, vc.psx, -vc.vw_half);
+    const float uvy = rt_fma<EXACT>(static_cast<float>(y) + 0.5f, vc.psy, -vc.vh_half);
+    const f3 draw = {uvx - cam.x, uvy - cam.y, 0.0f - cam.z};
+    const float dd = __builtin_fmaf(draw.z, draw.z, __builtin_fmaf(draw.y, draw.y, draw.x * draw.x));
+    const float h = __builtin_fmaf(draw.z, oc.z, __builtin_fmaf(draw.y, oc.y, draw.x * oc.x));
+    const float q = h * h;
 
-    // src/shapes.cpp:14-20 ; sphere.w holds radius*radius
-    const f3 oc = {sphere.x - cam.x, sphere.y - cam.y, sphere.z - cam.z};
-    const float a = dot3<EXACT>(d, d);
-    const float b = -2.0f * dot3<EXACT>(d, oc);
-    const float c = dot3<EXACT>(oc, oc) - sphere.w;
-    const float disc = rt_fma<EXACT>(-(4.0f * a), c, b * b);    // b*b - (4a)*c
+    if constexpr(EXACT) {
+        // Conservative miss test on the unnormalised ray (fused arithmetic): a quarter of the
+        // reference's discriminant has the sign of h*h - dd*c, and either evaluation is within
+        // about a dozen unit roundoffs of h*h + dd*(oc.oc + r*r); below -kScreenMargin of that
+        // magnitude the exact discriminant is negative too and the pixel is background.
+        const float screen = __builtin_fmaf(kScreenMargin, __builtin_fmaf(dd, cc.magnitude, q), __builtin_fmaf(-dd, cc.c, q));
+        if(!(screen >= 0.0f)) return bg;
 
-    f3 rgb = bg;
-    if(disc >= 0.0f) {
+        const f3 d = normalize3<true>(draw);                        // src/ray.h:18-20
+        // src/shapes.cpp:14-20
+        const float a = dot3<true>(d, d);
+        const float b = -2.0f * dot3<true>(d, oc);
+        const float disc = b * b - (4.0f * a) * cc.c;
+        if(!(disc >= 0.0f)) return bg;
         // src/shapes.cpp:23-25 : nearest root, no range test
-        const float t = rt_div<EXACT>(-b - rt_sqrt<EXACT>(disc), 2.0f * a);
-        const f3 p = {rt_fma<EXACT>(d.x, t, cam.x), rt_fma<EXACT>(d.y, t, cam.y), rt_fma<EXACT>(d.z, t, cam.z)};
-        const f3 n = normalize3<EXACT>(f3{p.x - sphere.x, p.y - sphere.y, p.z - sphere.z});
-        rgb = f3{remap_unit(n.x), remap_unit(n.y), remap_unit(n.z)};
+        const float t = (-b - __builtin_sqrtf(disc)) / (2.0f * a);
+        const f3 p = {d.x * t + cam.x, d.y * t + cam.y, d.z * t + cam.z};
+        const f3 n = normalize3<true>(f3{p.x - ctr.x, p.y - ctr.y, p.z - ctr.z});
+        return f3{remap_unit(n.x), remap_unit(n.y), remap_unit(n.z)};
+    } else {
+        const float disc = __builtin_fmaf(-dd, cc.c, q);            // unnormalised ray: t runs along `draw`
+        if(!(disc >= 0.0f)) return bg;
+        const float t = (h - __builtin_amdgcn_sqrtf(disc)) * __builtin_amdgcn_rcpf(dd);
+        const f3 v = {__builtin_fmaf(draw.x, t, cam.x - ctr.x), __builtin_fmaf(draw.y, t, cam.y - ctr.y),
+                      __builtin_fmaf(draw.z, t, cam.z - ctr.z)};
+        const float half_inv = 0.5f * __builtin_amdgcn_rsqf(dot3<false>(v, v));
+        return f3{__builtin_fmaf(v.x, half_inv, 0.5f), __builtin_fmaf(v.y, half_inv, 0.5f), __builtin_fmaf(v.z, half_inv, 0.5f)};
     }
-    rgb_out = rgb;
-    return pack_argb32(rgb.x, rgb.y, rgb.z);
 }
 
-// Exact build note: "b*b - (4a)*c" above goes through rt_fma<true>(-(4a), c, b*b) =
-// (-(4a))*c + b*b, which rounds the product first and then the sum: the same two roundings as
-// b*b - (4a)*c, because negation is exact and x + (-y) == x - y in IEEE arithmetic.
-
 template <bool EXACT, bool VEC4>
-__global__ __launch_bounds__(kPrimaryBlock) void primary_kernel(view_consts vc, float4 sphere,
+__global__ __launch_bounds__(kPrimaryBlock) void primary_kernel(view_consts vc, camera_consts cc,
                                                                  uint32_t *__restrict__ argb,
                                                                  float4 *__restrict__ rgba) {
     constexpr uint32_t PX = VEC4 ? 4u : 1u;
@@ -269,7 +297,10 @@ __global__ __launch_bounds__(kPrimaryBlock) void primary_kernel(view_consts vc, 
     uint32_t packed[PX];
     f3 rgb[PX];
 #pragma unroll
-    for(uint32_t i = 0; i < PX; i++) packed[i] = primary_pixel<EXACT>(vc, sphere, x0 + i, y, bg, rgb[i]);
+    for(uint32_t i = 0; i < PX; i++) {
+        rgb[i] = primary_pixel<EXACT>(vc, cc, x0 + i, y, bg);
+        packed[i] = pack_argb32(rgb[i].x, rgb[i].y, rgb[i].z);
+    }
 
     const size_t base = static_cast<size_t>(row) * vc.width + x0;
     if constexpr(VEC4) {
@@ -327,8 +358,6 @@ __device__ __forceinline__ void start_path(const view_consts &vc, uint32_t pix_t
 //                bound, so a negative screening value implies a negative exact discriminant:
 //                the sphere cannot change the result.  Spheres that pass are resolved with the
 //                reference's operation order, which decides.
-constexpr float kScreenMargin = 3e-5f;
-
 template <bool EXACT>
 __device__ __forceinline__ float screen_sphere(const float4 g, const f3 o, const f3 d, float &h_out) {
     const f3 oc = {g.x - o.x, g.y - o.y, g.z - o.z};
@@ -649,13 +678,6 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
 // iteration ahead.  Results are the same bits as path_kernel's (exact build) for such scenes.
 // ------------------------------------------------------------------------------------------
 
-struct camera_consts {       // ONE sphere: its constants travel as kernel arguments (SGPRs)
-    float oc[3];
-    float c;                 // oc.oc - r*r
-    float center[3];
-    float magnitude;         // oc.oc + r*r: size of the terms behind c, for the screening margin
-};
-
 template <bool EXACT, bool ONE>
 __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_consts cc, const float4 *__restrict__ geom,
                                                         const uint32_t *__restrict__ sample_terms,
@@ -871,7 +893,6 @@ struct aehip_backend {
 
     aehip_params params{};
     view_consts vc{};
-    float4 sphere0{};                        // primary pass: centre xyz, w = r*r
     bool all_terminal = false;               // every material ends the path: camera_kernel applies
     camera_consts cc{};                      // sphere 0 relative to the camera (camera_kernel, ONE)
 
@@ -909,10 +930,10 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         const bool vec4 = (vc.width % 4u) == 0 && (reinterpret_cast<uintptr_t>(argb_dev) % 16u) == 0;
         const uint64_t groups = static_cast<uint64_t>(vc.width / (vec4 ? 4u : 1u)) * vc.row_count;
         const dim3 grid(static_cast<uint32_t>((groups + kPrimaryBlock - 1) / kPrimaryBlock));
-        if(exact && vec4) { func = reinterpret_cast<const void *>(primary_kernel<true, true>); hipLaunchKernelGGL((primary_kernel<true, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->sphere0, argb_dev, rgba); }
-        else if(exact) { func = reinterpret_cast<const void *>(primary_kernel<true, false>); hipLaunchKernelGGL((primary_kernel<true, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->sphere0, argb_dev, rgba); }
-        else if(vec4) { func = reinterpret_cast<const void *>(primary_kernel<false, true>); hipLaunchKernelGGL((primary_kernel<false, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->sphere0, argb_dev, rgba); }
-        else { func = reinterpret_cast<const void *>(primary_kernel<false, false>); hipLaunchKernelGGL((primary_kernel<false, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->sphere0, argb_dev, rgba); }
+        if(exact && vec4) { func = reinterpret_cast<const void *>(primary_kernel<true, true>); hipLaunchKernelGGL((primary_kernel<true, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba); }
+        else if(exact) { func = reinterpret_cast<const void *>(primary_kernel<true, false>); hipLaunchKernelGGL((primary_kernel<true, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba); }
+        else if(vec4) { func = reinterpret_cast<const void *>(primary_kernel<false, true>); hipLaunchKernelGGL((primary_kernel<false, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba); }
+        else { func = reinterpret_cast<const void *>(primary_kernel<false, false>); hipLaunchKernelGGL((primary_kernel<false, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba); }
     } else if(b->all_terminal && vc.n_spheres <= static_cast<uint32_t>(kLdsSpheres)) {
         const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + kTileH - 1) / kTileH);
         const bool one = vc.n_spheres == 1;
@@ -1117,7 +1138,6 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
             matl[i] = make_float4(s.albedo[0], s.albedo[1], s.albedo[2], s.param);
             kind[i] = s.material;
         }
-        b->sphere0 = geom[0];
         b->all_terminal = true;
         for(uint32_t i = 0; i < n; i++) b->all_terminal = b->all_terminal && kind[i] == AEHIP_MAT_NORMAL;
         {
