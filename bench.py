@@ -22,7 +22,8 @@ The line also carries
                 timed on this host's cores on a bounded sample of the same frame, plus the real
                 reference binary's 1-sample figure where oracle/_ref was shipped,
   aux           (N=1, unless --no-aux) the reference-pinned primary pass at 4K against HBM store
-                bandwidth, and the 2,000-sphere brute-force scene against the FP32 vector peak.
+                bandwidth, the 10,000-sphere brute-force scene against the FP32 vector peak, and the
+                divergence-heavy scene's lane utilisation with and without path regeneration.
 """
 import argparse
 import json
@@ -261,12 +262,13 @@ def aux_measurements(rt, torch, stream):
                      "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": nbytes,
                      "note": "33 MB store per launch; launches back to back, so the figure includes launch gaps"},
     }
-    # brute-force list: 2,000 spheres, primary rays only, 18 flop per ray-sphere test
-    sph = scenes.stress_scene(2000, 42)
+    # brute-force list (config "~10k random spheres"): every ray tests every sphere, 18 flop per test;
+    # primary rays only so that every lane is busy and the figure is the intersection loop's own
+    sph = scenes.stress_scene(10000, 42)
     for mode in ("fast", "exact"):
         back = rt.HipRaytracer(None)
         flags = rt.FLAG_JITTER | rt.FLAG_COUNT_RAYS | (rt.FLAG_FAST if mode == "fast" else 0)
-        back.setup(1920, 1080, spp=4, max_depth=1, seed=1, flags=flags, pass_=rt.PASS_PATH, spheres=sph)
+        back.setup(1920, 1080, spp=2, max_depth=1, seed=1, flags=flags, pass_=rt.PASS_PATH, spheres=sph)
         img = torch.zeros((1080, 1920), dtype=torch.int32, device="cuda")
         best = None
         for _ in range(3):
@@ -276,10 +278,30 @@ def aux_measurements(rt, torch, stream):
             best = s.kernel_ms if best is None else min(best, s.kernel_ms)
         tests = s.rays * len(sph)
         tf = tests * 18.0 / (best * 1e-3) / 1e12
-        out[f"stress2k_1080p_4spp_depth1_{mode}"] = {
+        out[f"stress10k_1080p_2spp_depth1_{mode}"] = {
             "kernel_ms": best, "sphere_tests_per_s": tests / (best * 1e-3), "mpaths_per_s": s.paths / best / 1e3,
+            "rays_per_s": s.rays / (best * 1e-3),
             "roofline": {"bound": "valu_fp32", "achieved": tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf / FP32_VECTOR_PEAK_TFLOPS},
+                         "frac": tf / FP32_VECTOR_PEAK_TFLOPS, "kernel": "path_kernel (scalar-cache list stream)"},
+        }
+        back.close()
+    # divergence-heavy scene (mixed diffuse / metal / dielectric, depth 50): lane utilisation of the
+    # bounce loop with and without path regeneration
+    sph = scenes.divergence_scene(300, 7)
+    for regen in (True, False):
+        back = rt.HipRaytracer(None)
+        flags = rt.FLAG_JITTER | rt.FLAG_COUNT_RAYS | rt.FLAG_FAST | (0 if regen else rt.FLAG_NO_REGEN)
+        back.setup(1920, 1080, spp=16, max_depth=50, seed=7, flags=flags, pass_=rt.PASS_PATH, spheres=sph)
+        img = torch.zeros((1080, 1920), dtype=torch.int32, device="cuda")
+        best = None
+        for _ in range(2):
+            back.trace_device(img.data_ptr(), None, stream)
+            torch.cuda.synchronize()
+            s = back.stats()
+            best = s.kernel_ms if best is None else min(best, s.kernel_ms)
+        out["divergence_1080p_16spp_depth50_fast" + ("" if regen else "_no_regeneration")] = {
+            "kernel_ms": best, "mpaths_per_s": s.paths / best / 1e3, "rays_per_s": s.rays / (best * 1e-3),
+            "rays_per_path": s.rays / s.paths, "lane_utilisation": s.rays / s.lane_slots,
         }
         back.close()
     return out

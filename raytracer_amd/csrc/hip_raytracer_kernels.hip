@@ -39,6 +39,7 @@ constexpr int kBlock = kTileW * kTileH;
 constexpr int kLdsSpheres = 2048;        // shape-list chunk staged in LDS: 2048 x 16 B = 32 KiB
 constexpr int kPrimaryBlock = 256;       // primary pass: 256 threads x 4 pixels each
 constexpr float kTMin = 0.001f;
+constexpr uint32_t kPoolMinSpheres = 16;  // fast build: shape lists at least this long use the pooled path pass
 
 struct view_consts {
     float vw_half, vh_half;     // viewport_size * 0.5 (exact: power-of-two scale)
@@ -670,6 +671,129 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
 }
 
 // ------------------------------------------------------------------------------------------
+// pooled path pass (fast build): the wave, not the lane, owns the pixels.
+//
+// A wave's 16x4 pixel strip times spp samples is a pool of 64*spp work items; item i is sample
+// i/64 of pixel i%64, so the first 64 items are the strip's coherent first samples.  Whenever
+// lanes finish their paths, a ballot counts them and the next items of the pool are dealt out in
+// lane order (prefix popcount of the ballot; the pool cursor is wave-uniform, no atomics), so
+// every lane stays busy until the pool is empty whatever the spread of path lengths -- with one
+// lane per pixel (path_kernel) a lane whose pixel is finished idles until its wave's slowest
+// pixel is.  Finished paths add their radiance to per-pixel accumulators in LDS (ds_add_f32);
+// lane l resolves pixel l at the end.  The order in which a pixel's samples are summed depends on
+// path lengths, so this pass serves the fast build only; the exact build keeps per-lane
+// sequential sums (path_kernel).
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(kBlock) void path_pool_kernel(view_consts vc, const float4 *__restrict__ geom,
+                                                           const float4 *__restrict__ matl,
+                                                           const uint32_t *__restrict__ kind,
+                                                           const uint32_t *__restrict__ sample_terms,
+                                                           uint32_t *__restrict__ argb, float4 *__restrict__ rgba,
+                                                           unsigned long long *ray_counter) {
+    constexpr int kWaves = kBlock / 64;
+    __shared__ float s_acc[kWaves][3][64];
+    __shared__ uint32_t s_term[kWaves][64];          // per-pixel key terms of the wave's strip
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    const uint32_t x_base = blockIdx.x * kTileW;
+    const uint32_t row_base = blockIdx.y * kTileH + wave * 4u;       // the wave's strip: 16 px wide, 4 rows tall
+
+    s_acc[wave][0][lane] = 0.0f;
+    s_acc[wave][1][lane] = 0.0f;
+    s_acc[wave][2][lane] = 0.0f;
+    s_term[wave][lane] = pixel_term(vc.seed_hash, (vc.row_begin + row_base + (lane >> 4)) * vc.width + x_base + (lane & 15u));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const uint32_t pool = 64u * vc.spp;
+    uint32_t cursor = 0;             // next undealt item (wave-uniform)
+    uint32_t nrays = 0, iterations = 0;
+    uint32_t pix = 0, y = 0;
+    bool tracing = false, need = true;
+    path_state ps;
+    ps.o = ps.d = ps.thr = f3{0.0f, 0.0f, 0.0f};
+    ps.rng = 0;
+    ps.bounce = 0;
+
+    for(;;) {
+        // deal items to the lanes that need one
+        const unsigned long long want = __ballot(need);
+        if(want != 0ull) {
+            const uint32_t before = __builtin_popcountll(want & ((1ull << lane) - 1ull));
+            const uint32_t item = cursor + before;
+            cursor += static_cast<uint32_t>(__builtin_popcountll(want));
+            if(need) {
+                need = false;
+                if(item < pool) {
+                    pix = item & 63u;
+                    const uint32_t sample = item >> 6;
+                    const uint32_t x = x_base + (pix & 15u);
+                    const uint32_t row = row_base + (pix >> 4);
+                    y = vc.row_begin + row;
+                    if(x < vc.width && row < vc.row_count) {
+                        start_path<false>(vc, s_term[wave][pix], sample_terms, x, y, sample, ps);
+                        tracing = true;
+                    } else {
+                        need = true;            // item of a pixel outside the image: take another next round
+                    }
+                }
+            }
+        }
+        if(!__any(tracing || need)) break;
+        if(!__any(tracing)) {
+            if(cursor >= pool) break;           // only out-of-image items were left
+            continue;
+        }
+        iterations++;
+
+        float closest = 3.402823466e+38f;
+        int hit = -1;
+        if(tracing) {
+            intersect_chunk<false>(geom, vc.n_spheres, 0, ps.o, ps.d, 2.0f, 4.0f, closest, hit);
+            nrays++;
+            f3 L;
+            if(shade_segment<false>(vc, y, hit, closest, geom, matl, kind, ps, L)) {
+                if(L.x != 0.0f || L.y != 0.0f || L.z != 0.0f) {
+                    atomicAdd(&s_acc[wave][0][pix], L.x);
+                    atomicAdd(&s_acc[wave][1][pix], L.y);
+                    atomicAdd(&s_acc[wave][2][pix], L.z);
+                }
+                tracing = false;
+                need = true;
+            }
+        }
+    }
+
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+        const uint32_t x = x_base + (lane & 15u);
+        const uint32_t row = row_base + (lane >> 4);
+        if(x < vc.width && row < vc.row_count) {
+            const float inv = __builtin_amdgcn_rcpf(static_cast<float>(vc.spp));
+            const float r = clamp01(s_acc[wave][0][lane] * inv);
+            const float g = clamp01(s_acc[wave][1][lane] * inv);
+            const float b = clamp01(s_acc[wave][2][lane] * inv);
+            const size_t idx = static_cast<size_t>(row) * vc.width + x;
+            argb[idx] = pack_argb32(r, g, b);
+            if(rgba) rgba[idx] = make_float4(r, g, b, 1.0f);
+        }
+    }
+
+    if(vc.flags & AEHIP_FLAG_COUNT_RAYS) {
+        uint32_t v = nrays;
+#pragma unroll
+        for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if(lane == 0) {
+            atomicAdd(ray_counter, static_cast<unsigned long long>(v));
+            atomicAdd(ray_counter + 1, 64ull * iterations);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // camera pass: the path pass specialised for scenes in which every surface ends the path
 // (all materials NORMAL -- the reference's scene).  Every path is one segment from the camera,
 // so the sample loop is wave-uniform, the per-sphere terms that only depend on the ray origin
@@ -954,7 +1078,13 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         hipLaunchKernelGGL((path_kernel<E, L>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind,    \
                            b->d_sample_terms, argb_dev, rgba, b->d_rays);                                              \
     } while(0)
-        if(exact) {
+        // The pooled pass pays a few LDS operations per path; it wins once a segment costs more
+        // than that, i.e. for all but the smallest shape lists.
+        if(!exact && list == kListScalar && !(vc.flags & AEHIP_FLAG_NO_REGEN) && vc.n_spheres >= kPoolMinSpheres) {
+            func = reinterpret_cast<const void *>(path_pool_kernel);
+            hipLaunchKernelGGL(path_pool_kernel, grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind,
+                               b->d_sample_terms, argb_dev, rgba, b->d_rays);
+        } else if(exact) {
             if(list == kListLdsOnce) AEHIP_LAUNCH_PATH(true, kListLdsOnce);
             else if(list == kListLdsChunked) AEHIP_LAUNCH_PATH(true, kListLdsChunked);
             else AEHIP_LAUNCH_PATH(true, kListScalar);

@@ -262,3 +262,30 @@ def test_regeneration_keeps_lanes_busy_and_never_changes_the_image():
     util_on, util_off = st_on.rays / st_on.lane_slots, st_off.rays / st_off.lane_slots
     assert 0.0 < util_off < util_on <= 1.0
     assert util_on >= 1.25 * util_off
+
+
+def test_pooled_fast_pass_traces_the_same_paths_as_the_per_lane_pass():
+    """The fast build deals (pixel, sample) items to lanes by ballot; the paths are keyed by
+    (pixel, sample) so they are the same paths as the one-lane-per-pixel pass (selected here with
+    no_regen), summed in another order: equal ray counts, colours equal to float rounding."""
+    sph = scenes.divergence_scene()
+    w, h = 200, 120          # not a multiple of the 16x16 tile: exercises out-of-image items
+    flags = dict(spp=8, max_depth=50, seed=7, jitter=True, spheres=sph, count_rays=True, fast=True)
+    _, pooled, st_pool = render_device(w, h, **flags)
+    back = rt.HipRaytracer(None)
+    import torch
+
+    try:
+        f = rt.FLAG_JITTER | rt.FLAG_FAST | rt.FLAG_COUNT_RAYS | rt.FLAG_NO_REGEN
+        assert back.setup(w, h, 8, 50, 7, f, rt.PASS_PATH, spheres=sph)
+        argb = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+        rgba = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        back.trace_device(argb.data_ptr(), rgba.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        st_lane = back.stats()
+        per_lane = rgba.cpu().numpy()
+    finally:
+        back.close()
+    assert st_pool.rays == st_lane.rays
+    assert float(np.max(np.abs(pooled - per_lane))) <= 2e-6
+    assert st_pool.rays / st_pool.lane_slots > st_lane.rays / st_lane.lane_slots

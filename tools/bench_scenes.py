@@ -23,6 +23,8 @@ CASES = {
     "showcase_1080p_64spp_d8": (1920, 1080, 64, 8, scenes.showcase_scene),
     "stress10k_640x360_1spp_d4": (640, 360, 1, 4, lambda: scenes.stress_scene(10000, 42)),
     "stress10k_640x360_16spp_d4": (640, 360, 16, 4, lambda: scenes.stress_scene(10000, 42)),
+    "stress10k_1080p_4spp_d4": (1920, 1080, 4, 4, lambda: scenes.stress_scene(10000, 42)),
+    "stress10k_1080p_2spp_d1": (1920, 1080, 2, 1, lambda: scenes.stress_scene(10000, 42)),
     "stress2k_1080p_1spp_d1": (1920, 1080, 1, 1, lambda: scenes.stress_scene(2000, 42)),
     "stress2k_1080p_1spp_d4": (1920, 1080, 1, 4, lambda: scenes.stress_scene(2000, 42)),
     "stress2k_1080p_16spp_d4": (1920, 1080, 16, 4, lambda: scenes.stress_scene(2000, 42)),
