@@ -39,6 +39,7 @@ constexpr int kBlock = kTileW * kTileH;
 constexpr int kLdsSpheres = 2048;        // shape-list chunk staged in LDS: 2048 x 16 B = 32 KiB
 constexpr int kPrimaryBlock = 256;       // primary pass: 256 threads x 4 pixels each
 constexpr float kTMin = 0.001f;
+constexpr uint32_t kFlagFoldScreen = 1u << 31;   // internal: screening rays may use folded per-pixel terms
 constexpr uint32_t kPoolMinSpheres = 16;  // fast build: shape lists at least this long use the pooled path pass
 
 struct view_consts {
@@ -802,7 +803,7 @@ __global__ __launch_bounds__(kBlock) void path_pool_kernel(view_consts vc, const
 // iteration ahead.  Results are the same bits as path_kernel's (exact build) for such scenes.
 // ------------------------------------------------------------------------------------------
 
-template <bool EXACT, bool ONE>
+template <bool EXACT, bool ONE, bool FOLD>
 __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_consts cc, const float4 *__restrict__ geom,
                                                         const uint32_t *__restrict__ sample_terms,
                                                         uint32_t *__restrict__ argb, float4 *__restrict__ rgba,
@@ -843,15 +844,26 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
         f3 sum = {0.0f, 0.0f, 0.0f};
 
         if constexpr(EXACT) {
-            uint32_t term = sample_terms[0];
-            for(uint32_t sample = 0; sample < vc.spp; sample++) {
-                const uint32_t key = pix_term + term;
-                term = sample_terms[sample + 1];        // next sample's term (table has one spare entry)
+            // screening ray with the per-pixel terms folded into one fma per coordinate (see below)
+            constexpr bool fold = FOLD;
+            const float ux0 = __builtin_fmaf(xb, vc.psx, -(vc.vw_half + cam.x));
+            const float uy0 = __builtin_fmaf(yb, vc.psy, -(vc.vh_half + cam.y));
+            const float sx = jscale * vc.psx, sy = jscale * vc.psy;
+            const float dz2 = dz * dz;
+
+            // the sample's ray exactly as the reference builds it (src/software_raytracer.cpp:218-221)
+            auto exact_draw = [&](uint32_t key) {
                 const float px = __builtin_fmaf(static_cast<float>(key >> 16), jscale, xb);
                 const float py = __builtin_fmaf(static_cast<float>(key & 0xffffu), jscale, yb);
                 const float uvx = px * vc.psx - vc.vw_half;
                 const float uvy = py * vc.psy - vc.vh_half;
-                const f3 draw = {uvx - cam.x, uvy - cam.y, dz};
+                return f3{uvx - cam.x, uvy - cam.y, dz};
+            };
+
+            uint32_t term = sample_terms[0];
+            for(uint32_t sample = 0; sample < vc.spp; sample++) {
+                const uint32_t key = pix_term + term;
+                term = sample_terms[sample + 1];        // next sample's term (table has one spare entry)
 
                 // Conservative miss test on the unnormalised ray in fused arithmetic.  With
                 // h = draw.oc and dd = draw.draw the reference's discriminant has the sign of
@@ -859,16 +871,33 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
                 // h*h + dd*(oc.oc + r*r), so a value below -kScreenMargin of that magnitude is
                 // negative in the exact evaluation as well, and the sample takes the row
                 // background whatever its direction is.  Everything else runs the exact
-                // arithmetic below.
-                const float dd = __builtin_fmaf(draw.z, draw.z, __builtin_fmaf(draw.y, draw.y, draw.x * draw.x));
+                // arithmetic below.  Where the camera is not close to the viewport plane (host
+                // check, kFlagFoldScreen) the screening ray comes from two fmas instead of the
+                // reference's six operations: it differs from the exact ray by a few ulps of the
+                // viewport extent, which moves the screening value by under 6e-6 of the
+                // magnitude -- inside the margin with room to spare.
+                f3 draw = {0.0f, 0.0f, dz};
+                float rx, ry;
+                if constexpr(fold) {
+                    rx = __builtin_fmaf(static_cast<float>(key >> 16), sx, ux0);
+                    ry = __builtin_fmaf(static_cast<float>(key & 0xffffu), sy, uy0);
+                } else {
+                    draw = exact_draw(key);
+                    rx = draw.x;
+                    ry = draw.y;
+                }
+                const float dd = __builtin_fmaf(ry, ry, __builtin_fmaf(rx, rx, dz2));
                 bool maybe = false;
                 for(uint32_t i = 0; i < n_spheres; i++) {
                     const float4 k = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
                     const float mag = ONE ? cc.magnitude : s_ctr[i].w;
-                    const float h = __builtin_fmaf(draw.z, k.z, __builtin_fmaf(draw.y, k.y, draw.x * k.x));
+                    const float h = __builtin_fmaf(ry, k.y, __builtin_fmaf(rx, k.x, dz * k.z));
                     const float q = h * h;
                     const float screen = __builtin_fmaf(kScreenMargin, __builtin_fmaf(dd, mag, q), __builtin_fmaf(-dd, k.w, q));
                     maybe = maybe || (screen >= 0.0f);
+                }
+                if constexpr(fold) {
+                    if(maybe) draw = exact_draw(key);
                 }
 
                 f3 L = bg;
@@ -1061,10 +1090,23 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
     } else if(b->all_terminal && vc.n_spheres <= static_cast<uint32_t>(kLdsSpheres)) {
         const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + kTileH - 1) / kTileH);
         const bool one = vc.n_spheres == 1;
-        if(exact && one) { func = reinterpret_cast<const void *>(camera_kernel<true, true>); hipLaunchKernelGGL((camera_kernel<true, true>), grid, dim3(kBlock), 0, stream, vc, b->cc, b->d_geom, b->d_sample_terms, argb_dev, rgba, b->d_rays); }
-        else if(exact) { func = reinterpret_cast<const void *>(camera_kernel<true, false>); hipLaunchKernelGGL((camera_kernel<true, false>), grid, dim3(kBlock), 0, stream, vc, b->cc, b->d_geom, b->d_sample_terms, argb_dev, rgba, b->d_rays); }
-        else if(one) { func = reinterpret_cast<const void *>(camera_kernel<false, true>); hipLaunchKernelGGL((camera_kernel<false, true>), grid, dim3(kBlock), 0, stream, vc, b->cc, b->d_geom, b->d_sample_terms, argb_dev, rgba, b->d_rays); }
-        else { func = reinterpret_cast<const void *>(camera_kernel<false, false>); hipLaunchKernelGGL((camera_kernel<false, false>), grid, dim3(kBlock), 0, stream, vc, b->cc, b->d_geom, b->d_sample_terms, argb_dev, rgba, b->d_rays); }
+        const bool fold = (vc.flags & kFlagFoldScreen) != 0;
+#define AEHIP_LAUNCH_CAMERA(E, O, F)                                                                                   \
+    do {                                                                                                               \
+        func = reinterpret_cast<const void *>(camera_kernel<E, O, F>);                                                 \
+        hipLaunchKernelGGL((camera_kernel<E, O, F>), grid, dim3(kBlock), 0, stream, vc, b->cc, b->d_geom,              \
+                           b->d_sample_terms, argb_dev, rgba, b->d_rays);                                              \
+    } while(0)
+        if(exact) {
+            if(one && fold) AEHIP_LAUNCH_CAMERA(true, true, true);
+            else if(one) AEHIP_LAUNCH_CAMERA(true, true, false);
+            else if(fold) AEHIP_LAUNCH_CAMERA(true, false, true);
+            else AEHIP_LAUNCH_CAMERA(true, false, false);
+        } else {
+            if(one) AEHIP_LAUNCH_CAMERA(false, true, false);
+            else AEHIP_LAUNCH_CAMERA(false, false, false);
+        }
+#undef AEHIP_LAUNCH_CAMERA
     } else {
         const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + kTileH - 1) / kTileH);
         // List source.  Measured on MI355X the scalar-cache stream is as fast as or faster than LDS
@@ -1238,7 +1280,14 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
     vc.spp = p.spp;
     vc.max_depth = p.max_depth;
     vc.seed_hash = pcg_hash(p.seed);
-    vc.flags = p.flags;
+    vc.flags = p.flags & ~kFlagFoldScreen;
+    {
+        // The folded screening ray is off from the exact one by a few ulps of the viewport extent
+        // (camera offset included); relative to the ray length, at least |camera.z|, that stays far
+        // inside the screening margin when the camera is not close to the viewport plane.
+        const float extent = std::fmax(vc.vw_half, vc.vh_half) + std::fmax(std::fabs(vc.cam[0]), std::fabs(vc.cam[1]));
+        if(std::fabs(vc.cam[2]) >= 0.25f * extent) vc.flags |= kFlagFoldScreen;
+    }
     vc.n_spheres = scene->sphere_count;
 
     // scene upload (replicated on every GPU that renders a band)

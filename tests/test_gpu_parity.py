@@ -126,6 +126,9 @@ CASES = {
     "divergence_depth50": dict(size=(96, 64), spp=4, max_depth=50, seed=7, jitter=True, spheres="divergence"),
     "portrait_showcase": dict(size=(36, 100), spp=2, max_depth=5, seed=5, jitter=True, spheres="showcase"),
     "stress_multichunk": dict(size=(48, 28), spp=1, max_depth=3, seed=42, jitter=True, spheres="stress3000"),
+    "camera_near_viewport_plane": dict(size=(128, 72), spp=8, max_depth=1, seed=2, jitter=True, spheres=None, cam=(0.3, -0.2, 0.05)),
+    "camera_offset": dict(size=(128, 72), spp=8, max_depth=1, seed=2, jitter=True, spheres=None, cam=(0.5, 0.25, 1.5)),
+    "camera_inside_sphere": dict(size=(64, 64), spp=4, max_depth=1, seed=2, jitter=True, spheres=None, cam=(0.1, 0.0, -1.6)),
     "grazing_depth20": dict(size=(128, 96), spp=8, max_depth=20, seed=13, jitter=True, spheres="grazing"),
     "stress_depth6": dict(size=(64, 40), spp=3, max_depth=6, seed=4, jitter=True, spheres="stress3000"),
 }
@@ -146,10 +149,11 @@ def test_path_pass_exact_is_bit_identical_to_oracle(name, source):
     c = CASES[name]
     w, h = c["size"]
     sph = case_spheres(c["spheres"])
+    extra = {"cam": c["cam"]} if "cam" in c else {}
     want_argb, want_rgba, want_rays, _ = oracle.trace_paths(w, h, spp=c["spp"], max_depth=c["max_depth"], seed=c["seed"],
-                                                            jitter=c["jitter"], spheres=sph, threads=8, want_rgba=True)
+                                                            jitter=c["jitter"], spheres=sph, threads=8, want_rgba=True, **extra)
     got_argb, got_rgba, st = render_device(w, h, spp=c["spp"], max_depth=c["max_depth"], seed=c["seed"],
-                                           jitter=c["jitter"], spheres=sph, count_rays=True, list_source=LIST_SOURCES[source])
+                                           jitter=c["jitter"], spheres=sph, count_rays=True, list_source=LIST_SOURCES[source], **extra)
     np.testing.assert_array_equal(got_rgba.view(np.uint32), want_rgba.view(np.uint32))
     np.testing.assert_array_equal(got_argb, want_argb)
     assert st.rays == want_rays
