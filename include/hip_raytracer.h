@@ -137,6 +137,19 @@ int aehip_backend_trace_device(aehip_backend *backend, uint32_t *argb_dev, float
 
 int aehip_backend_stats(aehip_backend *backend, aehip_stats *out);
 
+/* One frame on `n_devices` GPUs of this node, driven from the calling thread; the multi-GPU form
+ * of setup() + trace() (src/raytracer.h:25-26) for a host program that is one process, as the
+ * reference is (src/main.cpp:11-25).  The rows params->row_begin .. +row_count (0 = all) are cut
+ * into n_devices contiguous bands, band i is rendered on device i (scene replicated), the bands
+ * are gathered into device 0's copy of the image with one RCCL group of ncclSend / ncclRecv
+ * (librccl is loaded on first use), and the image is copied to `framebuffer`
+ * (width * row_count words, host memory).  The result does not depend on n_devices.
+ * n_devices may exceed the number of GPUs; bands that share device 0's GPU are then moved with
+ * device-to-device copies instead of RCCL.  `stats` is optional: kernel_ms is the slowest band's
+ * kernel time, rays / paths / lane_slots are summed over bands. */
+int aehip_trace_frame(int n_devices, const aehip_scene *scene, const aehip_params *params, uint32_t *framebuffer,
+                      aehip_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,6 +84,7 @@ EXPORTS = (
     "aehip_backend_trace",
     "aehip_backend_trace_device",
     "aehip_backend_stats",
+    "aehip_trace_frame",
 )
 
 
@@ -122,6 +123,8 @@ def load() -> ctypes.CDLL:
         L.aehip_backend_trace.argtypes = [vp]
         L.aehip_backend_trace_device.argtypes = [vp, vp, vp, vp]
         L.aehip_backend_stats.argtypes = [vp, ctypes.POINTER(AehipStats)]
+        L.aehip_trace_frame.argtypes = [ctypes.c_int, ctypes.POINTER(AehipScene), ctypes.POINTER(AehipParams), vp,
+                                        ctypes.POINTER(AehipStats)]
         _lib = L
     return _lib
 
@@ -231,4 +234,22 @@ def render(width, height, spp=1, max_depth=1, seed=1, jitter=False, fast=False, 
         st = rt.stats()
     finally:
         rt.close()
+    return fb, st
+
+
+def trace_frame(n_devices, width, height, spp=1, max_depth=1, seed=1, jitter=False, fast=False, count_rays=False,
+                pass_=PASS_PATH, row_begin=0, row_count=0, spheres=None, **scene_kw):
+    """One frame cut into n_devices row bands by the library itself (aehip_trace_frame): rendered
+    on n_devices GPUs of this node from this process, gathered on device 0, copied to host.
+    Returns (argb uint32 [rows, width], stats)."""
+    L = load()
+    _check(L.aehip_init(), "aehip_init")
+    rows = row_count if row_count else height - row_begin
+    fb = np.zeros((rows, width), dtype=np.uint32)
+    sc, keep = make_scene(spheres, **scene_kw)
+    flags = (FLAG_JITTER if jitter else 0) | (FLAG_FAST if fast else 0) | (FLAG_COUNT_RAYS if count_rays else 0)
+    p = AehipParams(width, height, row_begin, row_count, spp, max_depth, seed, flags, pass_)
+    st = AehipStats()
+    _check(L.aehip_trace_frame(n_devices, ctypes.byref(sc), ctypes.byref(p), fb.ctypes.data, ctypes.byref(st)), "aehip_trace_frame")
+    del keep
     return fb, st

@@ -16,6 +16,9 @@
 //   colour -> 0xAARRGGBB       src/color.cpp:96-105
 //   framebuffer layout         src/software_raytracer.cpp:94-108
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>       // types and prototypes only: librccl is opened with dlopen on first use
+
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -23,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "hip_raytracer.h"
 #include "rt_exact_math.h"
@@ -1019,6 +1023,8 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
 // host side: error reporting, backend object, C ABI
 // ------------------------------------------------------------------------------------------
 
+void release_frame_state();        // multi-device frame state, defined with aehip_trace_frame
+
 thread_local char g_error[512] = "";
 bool g_initialised = false;
 int g_device_count = 0;
@@ -1170,6 +1176,7 @@ int aehip_init(void) {
 }
 
 void aehip_terminate(void) {
+    release_frame_state();
     g_initialised = false;
     g_device_count = 0;
 }
@@ -1433,3 +1440,205 @@ int aehip_backend_stats(aehip_backend *b, aehip_stats *out) {
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// one frame on several devices from one host thread
+// ------------------------------------------------------------------------------------------
+
+namespace {
+
+struct rccl_api {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+struct frame_state {
+    std::vector<aehip_backend *> bands;      // one backend per logical device
+    std::vector<ncclComm_t> comms;           // valid when the devices are distinct GPUs
+    rccl_api rccl;
+};
+frame_state g_frame;
+
+void release_frame_state() {
+    for(ncclComm_t c : g_frame.comms)
+        if(c && g_frame.rccl.CommDestroy) (void)g_frame.rccl.CommDestroy(c);
+    g_frame.comms.clear();
+    for(aehip_backend *b : g_frame.bands) aehip_backend_destroy(b);
+    g_frame.bands.clear();
+    if(g_frame.rccl.lib) dlclose(g_frame.rccl.lib);
+    g_frame.rccl = rccl_api{};
+}
+
+int load_rccl(rccl_api &api) {
+    if(api.lib) return AEHIP_OK;
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if(!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if(!lib) return fail(AEHIP_E_HIP, "cannot load librccl: %s", dlerror());
+    api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(lib, "ncclGroupStart"));
+    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+    api.Send = reinterpret_cast<decltype(api.Send)>(dlsym(lib, "ncclSend"));
+    api.Recv = reinterpret_cast<decltype(api.Recv)>(dlsym(lib, "ncclRecv"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if(!api.CommInitAll || !api.CommDestroy || !api.GroupStart || !api.GroupEnd || !api.Send || !api.Recv || !api.GetErrorString) {
+        dlclose(lib);
+        return fail(AEHIP_E_HIP, "librccl lacks a required entry point");
+    }
+    api.lib = lib;
+    return AEHIP_OK;
+}
+
+#define AEHIP_RCCL_CHECK(api, expr)                                                                          \
+    do {                                                                                                     \
+        ncclResult_t r_ = (expr);                                                                            \
+        if(r_ != ncclSuccess) return fail(AEHIP_E_HIP, "%s failed: %s", #expr, (api).GetErrorString(r_));    \
+    } while(0)
+
+}  // namespace
+
+extern "C" int aehip_trace_frame(int n_devices, const aehip_scene *scene, const aehip_params *params,
+                                 uint32_t *framebuffer, aehip_stats *stats_out) {
+    if(!scene || !params || !framebuffer) return fail(AEHIP_E_INVALID, "aehip_trace_frame: null argument");
+    if(n_devices < 1 || n_devices > 64) return fail(AEHIP_E_INVALID, "n_devices %d out of range (1..64)", n_devices);
+    if(!g_initialised) {
+        const int rc = aehip_init();
+        if(rc != AEHIP_OK) return rc;
+    }
+    const int n = n_devices;
+    const int physical = g_device_count;
+    const bool distinct = n <= physical;                 // every band has a GPU of its own
+
+    aehip_params frame = *params;
+    if(frame.height == 0 || frame.width == 0) return fail(AEHIP_E_INVALID, "resolution %ux%u is empty", frame.width, frame.height);
+    if(frame.row_count == 0) {
+        if(frame.row_begin >= frame.height) return fail(AEHIP_E_INVALID, "row_begin %u outside image of %u rows", frame.row_begin, frame.height);
+        frame.row_count = frame.height - frame.row_begin;
+    }
+    if(frame.row_begin + static_cast<uint64_t>(frame.row_count) > frame.height) return fail(AEHIP_E_INVALID, "rows outside the image");
+    if(static_cast<uint32_t>(n) > frame.row_count) return fail(AEHIP_E_INVALID, "%d devices for %u rows", n, frame.row_count);
+
+    // backends, one per logical device, kept for later frames
+    while(static_cast<int>(g_frame.bands.size()) < n) {
+        aehip_backend *b = nullptr;
+        const int rc = aehip_backend_create(static_cast<int>(g_frame.bands.size()) % physical, nullptr, &b);
+        if(rc != AEHIP_OK) return rc;
+        g_frame.bands.push_back(b);
+    }
+    if(distinct && n > 1 && static_cast<int>(g_frame.comms.size()) != n) {
+        const int rc = load_rccl(g_frame.rccl);
+        if(rc != AEHIP_OK) return rc;
+        for(ncclComm_t c : g_frame.comms)
+            if(c) (void)g_frame.rccl.CommDestroy(c);
+        g_frame.comms.assign(static_cast<size_t>(n), nullptr);
+        std::vector<int> devs(static_cast<size_t>(n));
+        for(int i = 0; i < n; i++) devs[static_cast<size_t>(i)] = i;
+        AEHIP_RCCL_CHECK(g_frame.rccl, g_frame.rccl.CommInitAll(g_frame.comms.data(), n, devs.data()));
+    }
+
+    // band i = rows [bounds[i], bounds[i+1]) of the frame (sizes differ by at most one row)
+    std::vector<uint32_t> bounds(static_cast<size_t>(n) + 1);
+    for(int i = 0; i <= n; i++) bounds[static_cast<size_t>(i)] = static_cast<uint32_t>(static_cast<uint64_t>(frame.row_count) * static_cast<uint32_t>(i) / static_cast<uint32_t>(n));
+
+    for(int i = 0; i < n; i++) {
+        aehip_params p = frame;
+        p.row_begin = frame.row_begin + bounds[static_cast<size_t>(i)];
+        p.row_count = bounds[static_cast<size_t>(i) + 1] - bounds[static_cast<size_t>(i)];
+        const int rc = aehip_backend_setup(g_frame.bands[static_cast<size_t>(i)], scene, &p);
+        if(rc != AEHIP_OK) return rc;
+    }
+
+    // device 0 holds the whole frame and renders its band straight into it; peers render into
+    // band buffers of their own
+    aehip_backend *b0 = g_frame.bands[0];
+    const size_t frame_pixels = static_cast<size_t>(frame.width) * frame.row_count;
+    for(int i = 0; i < n; i++) {
+        aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
+        const size_t need = i == 0 ? frame_pixels : static_cast<size_t>(frame.width) * b->vc.row_count;
+        AEHIP_CHECK(hipSetDevice(b->device));
+        if(need > b->argb_capacity) {
+            if(b->d_argb) (void)hipFree(b->d_argb);
+            b->d_argb = nullptr; b->argb_capacity = 0;
+            AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_argb), need * sizeof(uint32_t)));
+            b->argb_capacity = need;
+        }
+    }
+    AEHIP_CHECK(hipSetDevice(b0->device));
+    if(frame_pixels > b0->staging_capacity) {
+        if(b0->h_staging) (void)hipHostFree(b0->h_staging);
+        b0->h_staging = nullptr; b0->staging_capacity = 0;
+        AEHIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&b0->h_staging), frame_pixels * sizeof(uint32_t), hipHostMallocDefault));
+        b0->staging_capacity = frame_pixels;
+    }
+
+    // render: every device at once, each on its own stream
+    for(int i = 0; i < n; i++) {
+        aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
+        AEHIP_CHECK(hipSetDevice(b->device));
+        AEHIP_CHECK(hipEventRecord(b->ev_begin, b->stream));
+        const int rc = launch(b, b->d_argb, nullptr, b->stream);       // band 0 starts at row 0 of the frame
+        if(rc != AEHIP_OK) return rc;
+        AEHIP_CHECK(hipEventRecord(b->ev_end, b->stream));
+    }
+
+    // gather the peers' bands into device 0's frame
+    if(n > 1 && distinct) {
+        rccl_api &api = g_frame.rccl;
+        AEHIP_RCCL_CHECK(api, api.GroupStart());
+        for(int i = 1; i < n; i++) {
+            aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
+            const size_t count = static_cast<size_t>(frame.width) * b->vc.row_count;
+            AEHIP_CHECK(hipSetDevice(b->device));
+            AEHIP_RCCL_CHECK(api, api.Send(b->d_argb, count, ncclUint32, 0, g_frame.comms[static_cast<size_t>(i)], b->stream));
+            AEHIP_CHECK(hipSetDevice(b0->device));
+            AEHIP_RCCL_CHECK(api, api.Recv(b0->d_argb + static_cast<size_t>(frame.width) * bounds[static_cast<size_t>(i)], count, ncclUint32, i,
+                                           g_frame.comms[0], b0->stream));
+        }
+        AEHIP_RCCL_CHECK(api, api.GroupEnd());
+    } else if(n > 1) {
+        for(int i = 1; i < n; i++) {
+            aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
+            const size_t bytes = static_cast<size_t>(frame.width) * b->vc.row_count * sizeof(uint32_t);
+            AEHIP_CHECK(hipSetDevice(b->device));
+            AEHIP_CHECK(hipMemcpyPeerAsync(b0->d_argb + static_cast<size_t>(frame.width) * bounds[static_cast<size_t>(i)], b0->device,
+                                           b->d_argb, b->device, bytes, b->stream));
+        }
+    }
+    for(int i = 1; i < n; i++) {
+        aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
+        AEHIP_CHECK(hipSetDevice(b->device));
+        AEHIP_CHECK(hipStreamSynchronize(b->stream));
+    }
+
+    // frame -> pinned staging -> caller's buffer
+    AEHIP_CHECK(hipSetDevice(b0->device));
+    AEHIP_CHECK(hipMemcpyAsync(b0->h_staging, b0->d_argb, frame_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, b0->stream));
+    AEHIP_CHECK(hipEventRecord(b0->ev_copy, b0->stream));
+    AEHIP_CHECK(hipStreamSynchronize(b0->stream));
+    std::memcpy(framebuffer, b0->h_staging, frame_pixels * sizeof(uint32_t));
+
+    if(stats_out) {
+        aehip_stats total{};
+        for(int i = 0; i < n; i++) {
+            aehip_stats st{};
+            const int rc = aehip_backend_stats(g_frame.bands[static_cast<size_t>(i)], &st);
+            if(rc != AEHIP_OK) return rc;
+            total.kernel_ms = st.kernel_ms > total.kernel_ms ? st.kernel_ms : total.kernel_ms;
+            total.rays += st.rays;
+            total.paths += st.paths;
+            total.lane_slots += st.lane_slots;
+            total.vgprs = st.vgprs;
+            total.lds_bytes = st.lds_bytes;
+        }
+        float ms = 0.0f;
+        if(hipEventElapsedTime(&ms, b0->ev_end, b0->ev_copy) == hipSuccess) total.copy_ms = ms;   // gather + copy, as seen by device 0
+        *stats_out = total;
+    }
+    return AEHIP_OK;
+}

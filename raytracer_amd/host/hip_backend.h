@@ -25,7 +25,11 @@ namespace ae {
         aehip_stats stats() const;
 
     private:
-        aehip_backend *backend_ = nullptr;
+        aehip_backend *backend_ = nullptr;       // single-device render
+        aehip_scene scene_{};                    // kept for the multi-device frame call
+        aehip_params params_{};
+        aehip_stats frame_stats_{};
+        u32 gpus_ = 1;
         std::string error_;
         bool traced_ = false;
     };

@@ -293,3 +293,27 @@ def test_pooled_fast_pass_traces_the_same_paths_as_the_per_lane_pass():
     assert st_pool.rays == st_lane.rays
     assert float(np.max(np.abs(pooled - per_lane))) <= 2e-6
     assert st_pool.rays / st_pool.lane_slots > st_lane.rays / st_lane.lane_slots
+
+
+# ------------------------------------------------------------------ one frame on several devices
+
+@pytest.mark.parametrize("bands", [1, 2, 3, 5])
+def test_trace_frame_is_independent_of_the_number_of_bands(bands):
+    """aehip_trace_frame cuts the frame into row bands itself.  On a box with fewer GPUs than
+    bands the bands share a GPU (device-to-device gather instead of RCCL); the orchestration,
+    the band arithmetic and the image are the same."""
+    want = next(e["sha256"] for e in META["images"] if (e["width"], e["height"]) == (1920, 1080))
+    img, st = rt.trace_frame(bands, 1920, 1080, pass_=rt.PASS_PRIMARY)
+    assert sha(img) == want
+    assert st.paths == 1920 * 1080
+
+    sph = scenes.showcase_scene()
+    whole, _ = rt.render(130, 75, spp=3, max_depth=6, seed=9, jitter=True, spheres=sph, count_rays=True)
+    split, st = rt.trace_frame(bands, 130, 75, spp=3, max_depth=6, seed=9, jitter=True, spheres=sph, count_rays=True)
+    np.testing.assert_array_equal(split, whole)
+    assert st.paths == 130 * 75 * 3 and st.rays > st.paths
+
+
+def test_trace_frame_rejects_more_bands_than_rows():
+    with pytest.raises(rt.HipRaytracerError):
+        rt.trace_frame(9, 64, 8, pass_=rt.PASS_PRIMARY)

@@ -100,3 +100,12 @@ def test_cli_bad_scene_file_is_an_error(tmp_path):
     (tmp_path / "bad.txt").write_text("sphere 0 0 -2 1 plastic 1 1 1 0\n")
     res = run_cli(tmp_path, "--scene", "bad.txt", "--width", "16", "--height", "16")
     assert res.returncode == 2 and "bad.txt:1" in res.stderr
+
+
+@pytest.mark.gpu
+def test_cli_gpus_beyond_the_box_is_an_error(tmp_path):
+    import torch
+
+    n = torch.cuda.device_count()
+    res = run_cli(tmp_path, "--width", "64", "--height", "64", "--gpus", str(n + 1))
+    assert res.returncode == 1 and "--gpus" in res.stderr
