@@ -317,3 +317,33 @@ def test_trace_frame_is_independent_of_the_number_of_bands(bands):
 def test_trace_frame_rejects_more_bands_than_rows():
     with pytest.raises(rt.HipRaytracerError):
         rt.trace_frame(9, 64, 8, pass_=rt.PASS_PRIMARY)
+
+
+# ------------------------------------------------------------------ ragged and tiny images
+
+@pytest.mark.parametrize("size", [(1, 1), (3, 2), (17, 5), (64, 1), (1, 70), (33, 47), (255, 3)])
+@pytest.mark.parametrize("scene", [None, "showcase"])
+def test_ragged_sizes_match_oracle(size, scene):
+    """Sizes that are not multiples of the 16x16 workgroup tile or of the 4-pixel store width
+    (the reference CLI never produces them, the C ABI accepts them): partial workgroups and the
+    scalar-store path must produce the oracle's bits."""
+    w, h = size
+    sph = case_spheres(scene)
+    for fast in (False, True):
+        want, _, rays, _ = oracle.trace_paths(w, h, spp=5, max_depth=4, seed=21, jitter=True, spheres=sph, threads=2)
+        got, st = rt.render(w, h, spp=5, max_depth=4, seed=21, jitter=True, spheres=sph, count_rays=True, fast=fast)
+        if not fast:
+            np.testing.assert_array_equal(got, want)
+            assert st.rays == rays
+        else:
+            assert np.abs(channels(got) - channels(want)).max() <= 24      # same paths up to rare branch flips
+    np.testing.assert_array_equal(rt.render(w, h, pass_=rt.PASS_PRIMARY)[0], oracle.trace_primary(w, h))
+
+
+def test_large_spp_and_band_at_image_bottom():
+    want, _, _, _ = oracle.trace_paths(64, 2160, spp=3, max_depth=1, seed=1, jitter=True, row_begin=2150, row_count=10, threads=2)
+    got, _ = rt.render(64, 2160, spp=3, max_depth=1, seed=1, jitter=True, row_begin=2150, row_count=10)
+    np.testing.assert_array_equal(got, want)
+    a, _ = rt.render(32, 16, spp=4096, max_depth=1, seed=1, jitter=True)
+    b, _, _, _ = oracle.trace_paths(32, 16, spp=4096, max_depth=1, seed=1, jitter=True, threads=4)
+    np.testing.assert_array_equal(a, b)
