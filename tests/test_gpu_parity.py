@@ -347,3 +347,35 @@ def test_large_spp_and_band_at_image_bottom():
     a, _ = rt.render(32, 16, spp=4096, max_depth=1, seed=1, jitter=True)
     b, _, _, _ = oracle.trace_paths(32, 16, spp=4096, max_depth=1, seed=1, jitter=True, threads=4)
     np.testing.assert_array_equal(a, b)
+
+
+# ------------------------------------------------------------------ randomised differential test
+
+def random_scene(rng, n):
+    s = np.zeros(n, dtype=rt.SPHERE_DTYPE)
+    s["center"][:, 0] = rng.uniform(-4, 4, n)
+    s["center"][:, 1] = rng.uniform(-2, 3, n)
+    s["center"][:, 2] = rng.uniform(-9, -0.5, n)
+    s["radius"] = rng.choice([0.05, 0.3, 0.7, 1.5, 40.0], n, p=[0.2, 0.35, 0.25, 0.15, 0.05]) * rng.uniform(0.5, 1.5, n)
+    s["material"] = rng.integers(0, 4, n)
+    s["albedo"] = rng.uniform(0.2, 1.0, (n, 3))
+    s["param"] = np.where(s["material"] == rt.MAT_DIELECTRIC, rng.uniform(1.1, 2.4, n), rng.uniform(0.0, 0.6, n))
+    return s
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scenes_exact_build_equals_oracle(seed):
+    """Random sphere soups (overlapping spheres, cameras inside spheres, tiny and huge radii, all
+    materials, both list sources): every packed word, float and the ray count must agree."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 33, 130]))
+    sph = random_scene(rng, n)
+    cam = (float(rng.uniform(-1, 1)), float(rng.uniform(-0.5, 0.5)), float(rng.choice([1.0, 0.3, 2.5, -1.0])))
+    w, h = int(rng.choice([24, 40, 61])), int(rng.choice([16, 33]))
+    kw = dict(spp=int(rng.choice([1, 3, 6])), max_depth=int(rng.choice([1, 2, 12])), seed=seed, jitter=bool(seed % 3))
+    want_argb, want_rgba, want_rays, _ = oracle.trace_paths(w, h, spheres=sph, threads=2, want_rgba=True, cam=cam, **kw)
+    for source in LIST_SOURCES.values():
+        got_argb, got_rgba, st = render_device(w, h, spheres=sph, count_rays=True, list_source=source, cam=cam, **kw)
+        np.testing.assert_array_equal(got_rgba.view(np.uint32), want_rgba.view(np.uint32))
+        np.testing.assert_array_equal(got_argb, want_argb)
+        assert st.rays == want_rays
