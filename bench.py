@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 WIDTH, HEIGHT = 3840, 2160
 FP32_VECTOR_PEAK_TFLOPS = 157.3     # MI355X datasheet FP32 vector peak (256 CU x 256 flop/clk x 2.4 GHz)
 FP32_FMA_MEASURED_TFLOPS = 108.0    # what back-to-back v_fma_f32 sustains on this part (tools/valu_peak.hip)
+FP32_UNFUSED_MEASURED_TFLOPS = 54.0 # v_mul_f32 / v_add_f32 issue rate: the ceiling of code that may not fuse (exact build)
 HBM_PEAK_GBS = 8000.0
 
 # Algorithmic FP32 flops of the default-scene path pass, counted on the reference's formulas with
@@ -219,6 +220,12 @@ def main():
             e2, k2, st2 = second
             steps2 = max(2, args.steps // 2)
             a2 = flops / k2 / 1e12
+            unfused_mode_rate = a2 if other == "exact" else achieved
+            line["roofline"]["ceilings"] = {
+                "datasheet_fp32_vector": FP32_VECTOR_PEAK_TFLOPS, "measured_v_fma_f32": FP32_FMA_MEASURED_TFLOPS,
+                "measured_unfused_mul_add": FP32_UNFUSED_MEASURED_TFLOPS,
+                "exact_build_vs_unfused_ceiling": unfused_mode_rate / FP32_UNFUSED_MEASURED_TFLOPS,
+            }
             line[other] = {
                 "value": paths_total / (e2 / steps2) / 1e6, "unit": "Mpaths/s", "ms_per_step": e2 / steps2 * 1e3,
                 "kernel_ms": k2 * 1e3, "steps": steps2,

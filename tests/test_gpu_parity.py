@@ -379,3 +379,35 @@ def test_random_scenes_exact_build_equals_oracle(seed):
         np.testing.assert_array_equal(got_rgba.view(np.uint32), want_rgba.view(np.uint32))
         np.testing.assert_array_equal(got_argb, want_argb)
         assert st.rays == want_rays
+
+
+# ------------------------------------------------------------------ the benchmark configurations themselves
+
+def test_config_1080p_64spp_depth8_matches_cpu_image():
+    """Default scene at 1920x1080, 64 spp, max depth 8 on one GPU against the CPU image: the exact
+    build is bit-identical; the fast build is held to 50 dB PSNR and one code value."""
+    w, h = 1920, 1080
+    want_argb, want_rgba, rays, _ = oracle.trace_paths(w, h, spp=64, max_depth=8, seed=1, jitter=True, threads=16, want_rgba=True)
+    got_argb, got_rgba, st = render_device(w, h, spp=64, max_depth=8, seed=1, jitter=True, count_rays=True)
+    np.testing.assert_array_equal(got_argb, want_argb)
+    np.testing.assert_array_equal(got_rgba.view(np.uint32), want_rgba.view(np.uint32))
+    assert st.rays == rays == w * h * 64
+    fast_argb, fast_rgba, _ = render_device(w, h, spp=64, max_depth=8, seed=1, jitter=True, fast=True)
+    assert psnr(fast_rgba[..., :3], want_rgba[..., :3]) >= 50.0
+    # a grazing sample may land on the other side of the silhouette: one flipped sample of 64
+    # moves a channel by at most 255/64 = 4 code values; everywhere else rounding moves at most 1
+    diff = np.abs(channels(fast_argb) - channels(want_argb)).max(axis=-1)
+    assert diff.max() <= 4
+    assert np.count_nonzero(diff > 1) <= 1e-4 * w * h
+
+
+@pytest.mark.parametrize("gpus", [1, 2, 4, 8])
+def test_config_4k_jitter_free_sub_case_is_the_reference_image_through_the_sampling_kernel(gpus):
+    """3840x2160 through the spp/depth kernel with one centred sample: every band split used for
+    1/2/4/8 GPUs must re-assemble to the reference's own image."""
+    w, h = 3840, 2160
+    want = next(e["sha256"] for e in META["images"] if (e["width"], e["height"]) == (w, h))
+    bounds = [h * g // gpus for g in range(gpus + 1)]
+    parts = [rt.render(w, h, spp=1, max_depth=8, pass_=rt.PASS_PATH, row_begin=bounds[g], row_count=bounds[g + 1] - bounds[g])[0]
+             for g in range(gpus)]
+    assert sha(np.concatenate(parts, axis=0)) == want
