@@ -82,8 +82,13 @@ __device__ __forceinline__ float rt_div(float a, float b) {
 
 template <bool EXACT>
 __device__ __forceinline__ float rt_sqrt(float a) {
-    if constexpr(EXACT) return __builtin_sqrtf(a);   // correctly rounded
-    else return __builtin_amdgcn_sqrtf(a);
+    if constexpr(EXACT) {
+        // hipcc's correctly rounded sequence.  (The shorter rt_exact::sqrt_tame needs a range test
+        // and a branch here; measured on the camera pass that costs more than it saves: 8.6 vs 8.0 ms.)
+        return __builtin_sqrtf(a);
+    } else {
+        return __builtin_amdgcn_sqrtf(a);
+    }
 }
 
 template <bool EXACT>
@@ -97,7 +102,7 @@ template <bool EXACT>
 __device__ __forceinline__ f3 normalize3(f3 v) {
     if constexpr(EXACT) {
         const float m = (v.x * v.x + v.y * v.y) + v.z * v.z;
-        if(rt_exact::tame3(v.x, v.y, v.z)) {
+        if(rt_exact::tame3_bounded(v.x, v.y, v.z)) {     // |components| <= 2^40 by the scene bounds checked at setup
             // same bits as the plain operators below (rt_exact_math.h), one reciprocal shared
             // by the three divisions
             const float n = rt_exact::sqrt_tame(m);
@@ -271,7 +276,7 @@ __device__ __forceinline__ f3 primary_pixel(const view_consts &vc, const camera_
         const float disc = b * b - (4.0f * a) * cc.c;
         if(!(disc >= 0.0f)) return bg;
         // src/shapes.cpp:23-25 : nearest root, no range test
-        const float t = (-b - __builtin_sqrtf(disc)) / (2.0f * a);
+        const float t = (-b - rt_sqrt<true>(disc)) / (2.0f * a);
         const f3 p = {d.x * t + cam.x, d.y * t + cam.y, d.z * t + cam.z};
         const f3 n = normalize3<true>(f3{p.x - ctr.x, p.y - ctr.y, p.z - ctr.z});
         return f3{remap_unit(n.x), remap_unit(n.y), remap_unit(n.z)};
@@ -391,7 +396,7 @@ __device__ __forceinline__ void resolve_sphere(const float4 g, int index, float 
         const float c = dot3<true>(oc, oc) - g.w;
         const float disc = b * b - a4 * c;
         if(!(disc >= 0.0f)) return;
-        const float sq = __builtin_sqrtf(disc);
+        const float sq = rt_sqrt<true>(disc);
         t_near = (-b - sq) / a2;
         t_far = (-b + sq) / a2;
     } else {
@@ -917,7 +922,7 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
                         const float b = -2.0f * dot3<true>(d, f3{k.x, k.y, k.z});
                         const float disc = b * b - a4 * k.w;
                         if(disc >= 0.0f) {
-                            const float sq = __builtin_sqrtf(disc);
+                            const float sq = rt_sqrt<true>(disc);
                             float t = (-b - sq) / a2;
                             bool ok = (t > kTMin) && (t < closest);
                             if(!ok) {
@@ -1248,15 +1253,15 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
     if(scene->sphere_count == 0 || !scene->spheres) return fail(AEHIP_E_INVALID, "scene has no spheres");
     // Coordinates must be finite and moderate: the kernels' screening tests assume that squared
     // distances stay far from the fp32 overflow range.
-    auto moderate = [](float v) { return std::isfinite(v) && std::fabs(v) <= 1e12f; };
+    auto moderate = [](float v) { return std::isfinite(v) && std::fabs(v) <= 1e11f; };
     for(int k = 0; k < 3; k++) {
-        if(!moderate(scene->camera_pos[k])) return fail(AEHIP_E_INVALID, "camera position is not finite or beyond 1e12");
+        if(!moderate(scene->camera_pos[k])) return fail(AEHIP_E_INVALID, "camera position is not finite or beyond 1e11");
     }
     for(uint32_t i = 0; i < scene->sphere_count; i++) {
         const aehip_sphere &sp = scene->spheres[i];
         if(sp.material > AEHIP_MAT_DIELECTRIC) return fail(AEHIP_E_INVALID, "sphere %u: unknown material %u", i, sp.material);
         if(!moderate(sp.center[0]) || !moderate(sp.center[1]) || !moderate(sp.center[2]) || !moderate(sp.radius))
-            return fail(AEHIP_E_INVALID, "sphere %u: centre or radius is not finite or beyond 1e12", i);
+            return fail(AEHIP_E_INVALID, "sphere %u: centre or radius is not finite or beyond 1e11", i);
     }
 
     AEHIP_CHECK(hipSetDevice(b->device));

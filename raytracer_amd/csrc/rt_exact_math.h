@@ -35,6 +35,13 @@ __device__ __forceinline__ bool tame3(float x, float y, float z) {
     return lo >= kTameLo && hi <= kTameHi;
 }
 
+// The same test for callers that already know |x|,|y|,|z| <= 2^40 (the renderer bounds every
+// scene coordinate by 1e11 < 2^37, so every vector it normalises is): only the small side is
+// left to check.
+__device__ __forceinline__ bool tame3_bounded(float x, float y, float z) {
+    return __builtin_fminf(__builtin_fminf(__builtin_fabsf(x), __builtin_fabsf(y)), __builtin_fabsf(z)) >= kTameLo;
+}
+
 // v_rcp_f32 (1 ulp) + one Newton step: the reciprocal the division sequence multiplies by
 __device__ __forceinline__ float refined_rcp(float y) {
     const float r = __builtin_amdgcn_rcpf(y);
@@ -55,6 +62,10 @@ __device__ __forceinline__ float div_tame(float x, float y) { return div_with_rc
 
 // sqrtf(m) for tame m > 0: v_sqrt_f32 is within 1 ulp; pick among {s-1ulp, s, s+1ulp} by the
 // sign of the exact residuals m - s_dn*s and m - s_up*s
+// sqrt_tame is valid for any finite m >= 2^-96 (below that hipcc's sequence rescales); callers
+// with possibly tiny or zero m test this first.
+constexpr float kSqrtTameLo = 0x1p-90f;
+
 __device__ __forceinline__ float sqrt_tame(float m) {
     float s = __builtin_amdgcn_sqrtf(m);
     const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);

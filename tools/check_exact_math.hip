@@ -56,6 +56,9 @@ __global__ __launch_bounds__(256) void check(unsigned round, unsigned long long 
         local[2] += __float_as_uint(rt_exact::sqrt_tame(m)) != __float_as_uint(__builtin_sqrtf(m));
         const float mn = __builtin_fabsf(xn);
         local[2] += __float_as_uint(rt_exact::sqrt_tame(mn)) != __float_as_uint(__builtin_sqrtf(mn));
+        // the whole range sqrt_tame is used on: 2^-90 up to the largest finite floats
+        const float mw = __builtin_fabsf(make_float(h1, 37, 254));
+        if(mw >= rt_exact::kSqrtTameLo) local[2] += __float_as_uint(rt_exact::sqrt_tame(mw)) != __float_as_uint(__builtin_sqrtf(mw));
     }
     for(int t = 0; t < 3; t++)
         if(local[t]) atomicAdd(&mismatch[t], static_cast<unsigned long long>(local[t]));
