@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--no-aux", action="store_true")
     ap.add_argument("--no-second-mode", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--watchdog", type=int, default=900,
+                    help="seconds after which a rank dumps its Python stacks and exits (0 = off)")
     return ap.parse_args()
 
 
@@ -111,6 +113,10 @@ def frame_flops(paths, pixels):
 
 def main():
     args = parse()
+    if args.watchdog > 0:
+        # a rank stuck in a collective leaves a stack trace and ends instead of holding the node
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
     import torch
     import torch.distributed as dist
 
@@ -124,18 +130,26 @@ def main():
         sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; BENCH_SHARE_GPUS=1 (rehearsals on a box with fewer GPUs than ranks) lets ranks
+    # share devices and moves the gather to gloo, since RCCL needs a GPU per rank
+    share = os.environ.get("BENCH_SHARE_GPUS") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     gather = BandGather(WIDTH, HEIGHT, device)
+    overlap = not share                 # gloo's asynchronous gather of device tensors does not complete here
     stream = torch.cuda.current_stream().cuda_stream
 
     def timed_run(mode, steps, warmup):
         """K steps of render-band + gather; returns (elapsed_s max over ranks, kernel_s max over ranks, stats)."""
         flags = rt.FLAG_JITTER | (rt.FLAG_FAST if mode == "fast" else 0)
-        back = rt.HipRaytracer(None, device=local_rank)
+        back = rt.HipRaytracer(None, device=dev_index)
         if not back.setup(WIDTH, HEIGHT, spp=args.spp, max_depth=args.depth, seed=1, flags=flags, pass_=rt.PASS_PATH,
                           row_begin=gather.row_begin, row_count=gather.rows):
             sys.exit("setup failed: " + back.last_error())
@@ -148,11 +162,14 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            band = gather.begin(i)              # alternating band buffers: the gather of frame i
-            ev[i][0].record()                   # overlaps the render of frame i+1
-            back.trace_device(band.data_ptr(), None, stream)
+            band = gather.begin(i) if overlap else gather.local
+            ev[i][0].record()                   # alternating band buffers: the gather of frame i
+            back.trace_device(band.data_ptr(), None, stream)    # overlaps the render of frame i+1
             ev[i][1].record()
-            gather.submit(i)
+            if overlap:
+                gather.submit(i)
+            else:
+                gather.gather()
         gather.finish()
         if world > 1:
             dist.barrier()

@@ -3,8 +3,8 @@
 // Built with -ffp-contract=off: the compiler never fuses a multiply into an add on its own.
 // "Exact" code paths therefore evaluate IEEE binary32 expressions in the order written, with
 // correctly rounded division and square root, and reproduce the reference's CPU results bit for
-// bit; "fast" code paths ask for fusion and hardware approximations explicitly (rt_fma, rt_rcp,
-// rt_rsq below).
+// bit; "fast" code paths ask for fusion and hardware approximations explicitly
+// (__builtin_fmaf, __builtin_amdgcn_rcpf / rsqf / sqrtf).
 //
 // Reference functions restated here (paths relative to the reference checkout):
 //   viewport set-up            src/software_raytracer.cpp:68-91
