@@ -151,7 +151,7 @@ def main():
         flags = rt.FLAG_JITTER | (rt.FLAG_FAST if mode == "fast" else 0)
         back = rt.HipRaytracer(None, device=dev_index)
         if not back.setup(WIDTH, HEIGHT, spp=args.spp, max_depth=args.depth, seed=1, flags=flags, pass_=rt.PASS_PATH,
-                          row_begin=gather.row_begin, row_count=gather.rows):
+                          **gather.band):
             sys.exit("setup failed: " + back.last_error())
         for _ in range(warmup):
             back.trace_device(gather.local.data_ptr(), None, stream)
@@ -189,7 +189,7 @@ def main():
 
     if rank == 0:
         paths_total = WIDTH * HEIGHT * args.spp
-        # the slowest rank renders 1/world of the frame (bands are equal at 1,2,4,8 GPUs)
+        # every rank renders 1/world of the frame, the same mix of rows (tiles dealt round-robin)
         flops = frame_flops(paths_total / world, WIDTH * HEIGHT / world)
         achieved = flops / kernel_s / 1e12
         line = {
@@ -207,7 +207,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"default scene {WIDTH}x{HEIGHT}, {args.spp} spp jittered, max depth {args.depth}, "
-                            f"row bands over {world} GPU(s), gather to rank 0",
+                            f"4-row tiles dealt round-robin to {world} GPU(s), gather to rank 0",
                 "arithmetic": args.mode,
                 "rays_per_path": 1,
             },

@@ -80,8 +80,9 @@ typedef struct aehip_scene {
 
 typedef struct aehip_params {
     uint32_t width, height;         /* what raytracer::get_resolution() returns (src/raytracer.cpp:18-34) */
-    uint32_t row_begin, row_count;  /* band of image rows this backend renders; row_count 0 = all rows.
-                                       Outputs hold row_count rows, first row = row_begin. */
+    uint32_t row_begin, row_count;  /* band of image rows this backend renders; row_count 0 = every row
+                                       of the band below `height`.  Outputs hold the band's row_count
+                                       rows densely, band row 0 = image row row_begin. */
     uint32_t spp;                   /* samples per pixel, >= 1 */
     uint32_t max_depth;             /* ray segments per path, >= 1 */
     uint32_t seed;
@@ -90,7 +91,14 @@ typedef struct aehip_params {
     uint32_t list_source;           /* where the path pass reads the shape list from: 0 = library's
                                        choice, 1 = staged in LDS per workgroup, 2 = streamed through
                                        the scalar cache.  Results are identical; only speed differs. */
-    uint32_t reserved[2];
+    uint32_t tile_rows;             /* 0: the band is the contiguous rows row_begin .. row_begin+row_count-1.
+                                       T > 0: the band is row tiles of T rows starting at image rows
+                                       row_begin, row_begin + tile_stride, row_begin + 2*tile_stride, ...
+                                       (band row j = image row row_begin + (j / T) * tile_stride + j % T);
+                                       tiles dealt round-robin to N GPUs (row_begin = g*T, tile_stride =
+                                       N*T) give every GPU the same mix of cheap and costly rows.  The
+                                       reference schedules tiles of 4 rows (src/raytracer.h:28). */
+    uint32_t tile_stride;           /* image rows between the first rows of consecutive tiles, >= tile_rows */
 } aehip_params;
 
 typedef struct aehip_stats {
@@ -140,10 +148,12 @@ int aehip_backend_stats(aehip_backend *backend, aehip_stats *out);
 /* One frame on `n_devices` GPUs of this node, driven from the calling thread; the multi-GPU form
  * of setup() + trace() (src/raytracer.h:25-26) for a host program that is one process, as the
  * reference is (src/main.cpp:11-25).  The rows params->row_begin .. +row_count (0 = all) are cut
- * into n_devices contiguous bands, band i is rendered on device i (scene replicated), the bands
- * are gathered into device 0's copy of the image with one RCCL group of ncclSend / ncclRecv
- * (librccl is loaded on first use), and the image is copied to `framebuffer`
- * (width * row_count words, host memory).  The result does not depend on n_devices.
+ * into tiles of params->tile_rows rows (0 = 4, the reference's tile height, src/raytracer.h:28)
+ * dealt round-robin to n_devices bands, band i is rendered on device i (scene replicated), the
+ * bands are gathered on device 0 with one RCCL group of ncclSend / ncclRecv (librccl is loaded on
+ * first use), and the rows are copied to their places in `framebuffer` (width * row_count words,
+ * host memory, image order).  params->tile_stride is ignored.  The result does not depend on
+ * n_devices or the tile height.
  * n_devices may exceed the number of GPUs; bands that share device 0's GPU are then moved with
  * device-to-device copies instead of RCCL.  `stats` is optional: kernel_ms is the slowest band's
  * kernel time, rays / paths / lane_slots are summed over bands. */

@@ -54,7 +54,8 @@ class AehipParams(ctypes.Structure):
         ("flags", ctypes.c_uint32),
         ("pass_", ctypes.c_uint32),
         ("list_source", ctypes.c_uint32),
-        ("reserved", ctypes.c_uint32 * 2),
+        ("tile_rows", ctypes.c_uint32),
+        ("tile_stride", ctypes.c_uint32),
     ]
 
 
@@ -181,14 +182,15 @@ class HipRaytracer:
         self.params = None
 
     def setup(self, width, height, spp=1, max_depth=1, seed=1, flags=0, pass_=PASS_PRIMARY, row_begin=0,
-              row_count=0, spheres=None, list_source=0, **scene_kw) -> bool:
+              row_count=0, spheres=None, list_source=0, tile_rows=0, tile_stride=0, **scene_kw) -> bool:
         sc, keep = make_scene(spheres, **scene_kw)
         p = AehipParams(width, height, row_begin, row_count, spp, max_depth, seed, flags, pass_)
         p.list_source = list_source      # 0 = library's choice, 1 = LDS staging, 2 = scalar-cache stream
+        p.tile_rows, p.tile_stride = tile_rows, tile_stride     # 0, 0 = contiguous band
         rc = self._lib.aehip_backend_setup(self._h, ctypes.byref(sc), ctypes.byref(p))
         del keep
         self.params = p
-        self.rows = row_count if row_count else height - row_begin
+        self.rows = row_count if row_count else band_row_count(height, row_begin, tile_rows, tile_stride)
         self.width = width
         return rc == 0
 
@@ -218,17 +220,28 @@ class HipRaytracer:
             pass
 
 
+def band_row_count(height, row_begin, tile_rows=0, tile_stride=0) -> int:
+    """Rows of the band that starts at row_begin and runs to the image's last row: every row
+    (tile_rows 0), or the rows of tiles of tile_rows rows placed every tile_stride rows."""
+    span = max(0, height - row_begin)
+    if tile_rows == 0:
+        return span
+    return span // tile_stride * tile_rows + min(span % tile_stride, tile_rows)
+
+
 def render(width, height, spp=1, max_depth=1, seed=1, jitter=False, fast=False, count_rays=False,
-           pass_=PASS_PATH, row_begin=0, row_count=0, spheres=None, device=0, no_regen=False, **scene_kw):
+           pass_=PASS_PATH, row_begin=0, row_count=0, spheres=None, device=0, no_regen=False,
+           tile_rows=0, tile_stride=0, **scene_kw):
     """One-shot helper: render a band into host memory through setup()/trace().
-    Returns (argb uint32 [rows, width], stats)."""
-    rows = row_count if row_count else height - row_begin
+    Returns (argb uint32 [rows, width] in band order, stats)."""
+    rows = row_count if row_count else band_row_count(height, row_begin, tile_rows, tile_stride)
     fb = np.zeros((rows, width), dtype=np.uint32)
     rt = HipRaytracer(fb, device)
     flags = (FLAG_JITTER if jitter else 0) | (FLAG_FAST if fast else 0) | (FLAG_COUNT_RAYS if count_rays else 0) \
         | (FLAG_NO_REGEN if no_regen else 0)
     try:
-        if not rt.setup(width, height, spp, max_depth, seed, flags, pass_, row_begin, row_count, spheres, **scene_kw):
+        if not rt.setup(width, height, spp, max_depth, seed, flags, pass_, row_begin, row_count, spheres,
+                        tile_rows=tile_rows, tile_stride=tile_stride, **scene_kw):
             raise HipRaytracerError("setup failed: " + rt.last_error())
         rt.trace()
         st = rt.stats()
@@ -238,10 +251,10 @@ def render(width, height, spp=1, max_depth=1, seed=1, jitter=False, fast=False, 
 
 
 def trace_frame(n_devices, width, height, spp=1, max_depth=1, seed=1, jitter=False, fast=False, count_rays=False,
-                pass_=PASS_PATH, row_begin=0, row_count=0, spheres=None, **scene_kw):
-    """One frame cut into n_devices row bands by the library itself (aehip_trace_frame): rendered
-    on n_devices GPUs of this node from this process, gathered on device 0, copied to host.
-    Returns (argb uint32 [rows, width], stats)."""
+                pass_=PASS_PATH, row_begin=0, row_count=0, spheres=None, tile_rows=0, **scene_kw):
+    """One frame cut into row tiles dealt to n_devices bands by the library itself
+    (aehip_trace_frame): rendered on n_devices GPUs of this node from this process, gathered on
+    device 0, copied to host in image order.  Returns (argb uint32 [rows, width], stats)."""
     L = load()
     _check(L.aehip_init(), "aehip_init")
     rows = row_count if row_count else height - row_begin
@@ -249,6 +262,7 @@ def trace_frame(n_devices, width, height, spp=1, max_depth=1, seed=1, jitter=Fal
     sc, keep = make_scene(spheres, **scene_kw)
     flags = (FLAG_JITTER if jitter else 0) | (FLAG_FAST if fast else 0) | (FLAG_COUNT_RAYS if count_rays else 0)
     p = AehipParams(width, height, row_begin, row_count, spp, max_depth, seed, flags, pass_)
+    p.tile_rows = tile_rows
     st = AehipStats()
     _check(L.aehip_trace_frame(n_devices, ctypes.byref(sc), ctypes.byref(p), fb.ctypes.data, ctypes.byref(st)), "aehip_trace_frame")
     del keep

@@ -54,6 +54,7 @@ struct view_consts {
     float bg1[3];
     uint32_t width, height;
     uint32_t row_begin, row_count;
+    uint32_t tile_rows, tile_stride;    // 0, 0: contiguous band; else row tiles dealt with a stride
     uint32_t spp, max_depth;
     uint32_t seed_hash;         // pcg_hash(seed), hoisted to the host
     uint32_t flags;
@@ -63,6 +64,13 @@ struct view_consts {
 struct f3 {
     float x, y, z;
 };
+
+// band row -> image row (aehip_params.tile_rows / tile_stride)
+__host__ __device__ __forceinline__ uint32_t image_row(const view_consts &vc, uint32_t row) {
+    if(vc.tile_rows == 0) return vc.row_begin + row;
+    const uint32_t tile = row / vc.tile_rows;
+    return vc.row_begin + tile * vc.tile_stride + (row - tile * vc.tile_rows);
+}
 
 // ------------------------------------------------------------------------------------------
 // arithmetic policy
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(kPrimaryBlock) void primary_kernel(view_consts vc, 
 
     const uint32_t row = gid / groups_per_row;
     const uint32_t x0 = (gid - row * groups_per_row) * PX;
-    const uint32_t y = vc.row_begin + row;
+    const uint32_t y = image_row(vc, row);
     const f3 bg = row_background<EXACT>(vc, y);
 
     uint32_t packed[PX];
@@ -580,7 +588,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
     const uint32_t tid = threadIdx.x;
     const uint32_t x = blockIdx.x * kTileW + (tid & (kTileW - 1));
     const uint32_t row = blockIdx.y * kTileH + (tid / kTileW);
-    const uint32_t y = vc.row_begin + row;
+    const uint32_t y = image_row(vc, row);
     const bool valid = (x < vc.width) && (row < vc.row_count);
 
     if constexpr(LIST == kListLdsOnce) {
@@ -713,7 +721,7 @@ __global__ __launch_bounds__(kBlock) void path_pool_kernel(view_consts vc, const
     s_acc[wave][0][lane] = 0.0f;
     s_acc[wave][1][lane] = 0.0f;
     s_acc[wave][2][lane] = 0.0f;
-    s_term[wave][lane] = pixel_term(vc.seed_hash, (vc.row_begin + row_base + (lane >> 4)) * vc.width + x_base + (lane & 15u));
+    s_term[wave][lane] = pixel_term(vc.seed_hash, image_row(vc, row_base + (lane >> 4)) * vc.width + x_base + (lane & 15u));
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -741,7 +749,7 @@ __global__ __launch_bounds__(kBlock) void path_pool_kernel(view_consts vc, const
                     const uint32_t sample = item >> 6;
                     const uint32_t x = x_base + (pix & 15u);
                     const uint32_t row = row_base + (pix >> 4);
-                    y = vc.row_begin + row;
+                    y = image_row(vc, row);
                     if(x < vc.width && row < vc.row_count) {
                         start_path<false>(vc, s_term[wave][pix], sample_terms, x, y, sample, ps);
                         tracing = true;
@@ -823,7 +831,7 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
     const uint32_t tid = threadIdx.x;
     const uint32_t x = blockIdx.x * kTileW + (tid & (kTileW - 1));
     const uint32_t row = blockIdx.y * kTileH + (tid / kTileW);
-    const uint32_t y = vc.row_begin + row;
+    const uint32_t y = image_row(vc, row);
     const bool valid = (x < vc.width) && (row < vc.row_count);
     const f3 cam = {vc.cam[0], vc.cam[1], vc.cam[2]};
     const uint32_t n_spheres = ONE ? 1u : vc.n_spheres;
@@ -1243,11 +1251,20 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
     aehip_params p = *params;
     if(p.width == 0 || p.height == 0) return fail(AEHIP_E_INVALID, "resolution %ux%u is empty", p.width, p.height);
     if(p.width > 65535u || p.height > 65535u) return fail(AEHIP_E_TOO_LARGE, "resolution %ux%u exceeds 65535 per side", p.width, p.height);
-    if(p.row_count == 0) {
-        if(p.row_begin >= p.height) return fail(AEHIP_E_INVALID, "row_begin %u outside image of %u rows", p.row_begin, p.height);
-        p.row_count = p.height - p.row_begin;
+    if(p.row_begin >= p.height) return fail(AEHIP_E_INVALID, "row_begin %u outside image of %u rows", p.row_begin, p.height);
+    if(p.tile_rows == 0) {
+        p.tile_stride = 0;
+        if(p.row_count == 0) p.row_count = p.height - p.row_begin;
+        if(p.row_begin + static_cast<uint64_t>(p.row_count) > p.height) return fail(AEHIP_E_INVALID, "rows [%u,%u) outside image of %u rows", p.row_begin, p.row_begin + p.row_count, p.height);
+    } else {
+        if(p.tile_stride < p.tile_rows) return fail(AEHIP_E_INVALID, "tile_stride %u is less than tile_rows %u", p.tile_stride, p.tile_rows);
+        // rows the band's tiles have below the image's last row
+        const uint32_t span = p.height - p.row_begin;
+        const uint32_t whole = span / p.tile_stride, rest = span % p.tile_stride;
+        const uint64_t avail = static_cast<uint64_t>(whole) * p.tile_rows + (rest < p.tile_rows ? rest : p.tile_rows);
+        if(p.row_count == 0) p.row_count = static_cast<uint32_t>(avail);
+        if(p.row_count > avail) return fail(AEHIP_E_INVALID, "%u rows in tiles of %u every %u rows from row %u leave the image of %u rows", p.row_count, p.tile_rows, p.tile_stride, p.row_begin, p.height);
     }
-    if(p.row_begin + static_cast<uint64_t>(p.row_count) > p.height) return fail(AEHIP_E_INVALID, "rows [%u,%u) outside image of %u rows", p.row_begin, p.row_begin + p.row_count, p.height);
     if(p.pass != AEHIP_PASS_PRIMARY && p.pass != AEHIP_PASS_PATH) return fail(AEHIP_E_INVALID, "unknown pass %u", p.pass);
     if(p.spp == 0 || p.max_depth == 0) return fail(AEHIP_E_INVALID, "spp and max_depth must be >= 1");
     if(scene->sphere_count == 0 || !scene->spheres) return fail(AEHIP_E_INVALID, "scene has no spheres");
@@ -1289,6 +1306,8 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
     vc.height = p.height;
     vc.row_begin = p.row_begin;
     vc.row_count = p.row_count;
+    vc.tile_rows = p.tile_rows;
+    vc.tile_stride = p.tile_stride;
     vc.spp = p.spp;
     vc.max_depth = p.max_depth;
     vc.seed_hash = pcg_hash(p.seed);
@@ -1527,7 +1546,11 @@ extern "C" int aehip_trace_frame(int n_devices, const aehip_scene *scene, const 
         frame.row_count = frame.height - frame.row_begin;
     }
     if(frame.row_begin + static_cast<uint64_t>(frame.row_count) > frame.height) return fail(AEHIP_E_INVALID, "rows outside the image");
-    if(static_cast<uint32_t>(n) > frame.row_count) return fail(AEHIP_E_INVALID, "%d devices for %u rows", n, frame.row_count);
+    // tiles of T rows dealt round-robin: band i = tiles i, i+n, i+2n, ... of the frame's rows, so
+    // that every device gets the same mix of cheap and costly rows
+    const uint32_t T = frame.tile_rows ? frame.tile_rows : 4u;
+    const uint32_t tiles = (frame.row_count + T - 1) / T;
+    if(static_cast<uint32_t>(n) > tiles) return fail(AEHIP_E_INVALID, "%d devices for %u tiles of %u rows", n, tiles, T);
 
     // backends, one per logical device, kept for later frames
     while(static_cast<int>(g_frame.bands.size()) < n) {
@@ -1547,20 +1570,27 @@ extern "C" int aehip_trace_frame(int n_devices, const aehip_scene *scene, const 
         AEHIP_RCCL_CHECK(g_frame.rccl, g_frame.rccl.CommInitAll(g_frame.comms.data(), n, devs.data()));
     }
 
-    // band i = rows [bounds[i], bounds[i+1]) of the frame (sizes differ by at most one row)
-    std::vector<uint32_t> bounds(static_cast<size_t>(n) + 1);
-    for(int i = 0; i <= n; i++) bounds[static_cast<size_t>(i)] = static_cast<uint32_t>(static_cast<uint64_t>(frame.row_count) * static_cast<uint32_t>(i) / static_cast<uint32_t>(n));
+    std::vector<uint32_t> band_rows(static_cast<size_t>(n)), offset(static_cast<size_t>(n) + 1, 0u);   // in rows
+    const uint32_t stride = static_cast<uint32_t>(n) * T;
+    for(int i = 0; i < n; i++) {
+        const uint32_t span = frame.row_count - static_cast<uint32_t>(i) * T;
+        const uint32_t whole = span / stride, rest = span % stride;
+        band_rows[static_cast<size_t>(i)] = whole * T + (rest < T ? rest : T);
+        offset[static_cast<size_t>(i) + 1] = offset[static_cast<size_t>(i)] + band_rows[static_cast<size_t>(i)];
+    }
 
     for(int i = 0; i < n; i++) {
         aehip_params p = frame;
-        p.row_begin = frame.row_begin + bounds[static_cast<size_t>(i)];
-        p.row_count = bounds[static_cast<size_t>(i) + 1] - bounds[static_cast<size_t>(i)];
+        p.row_begin = frame.row_begin + static_cast<uint32_t>(i) * T;
+        p.row_count = band_rows[static_cast<size_t>(i)];
+        p.tile_rows = n > 1 ? T : 0u;
+        p.tile_stride = n > 1 ? stride : 0u;
         const int rc = aehip_backend_setup(g_frame.bands[static_cast<size_t>(i)], scene, &p);
         if(rc != AEHIP_OK) return rc;
     }
 
-    // device 0 holds the whole frame and renders its band straight into it; peers render into
-    // band buffers of their own
+    // device 0 holds every band, densely, one after the other, and renders its own band straight
+    // into place; peers render into band buffers of their own
     aehip_backend *b0 = g_frame.bands[0];
     const size_t frame_pixels = static_cast<size_t>(frame.width) * frame.row_count;
     for(int i = 0; i < n; i++) {
@@ -1587,7 +1617,7 @@ extern "C" int aehip_trace_frame(int n_devices, const aehip_scene *scene, const 
         aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
         AEHIP_CHECK(hipSetDevice(b->device));
         AEHIP_CHECK(hipEventRecord(b->ev_begin, b->stream));
-        const int rc = launch(b, b->d_argb, nullptr, b->stream);       // band 0 starts at row 0 of the frame
+        const int rc = launch(b, b->d_argb, nullptr, b->stream);
         if(rc != AEHIP_OK) return rc;
         AEHIP_CHECK(hipEventRecord(b->ev_end, b->stream));
     }
@@ -1602,7 +1632,7 @@ extern "C" int aehip_trace_frame(int n_devices, const aehip_scene *scene, const 
             AEHIP_CHECK(hipSetDevice(b->device));
             AEHIP_RCCL_CHECK(api, api.Send(b->d_argb, count, ncclUint32, 0, g_frame.comms[static_cast<size_t>(i)], b->stream));
             AEHIP_CHECK(hipSetDevice(b0->device));
-            AEHIP_RCCL_CHECK(api, api.Recv(b0->d_argb + static_cast<size_t>(frame.width) * bounds[static_cast<size_t>(i)], count, ncclUint32, i,
+            AEHIP_RCCL_CHECK(api, api.Recv(b0->d_argb + static_cast<size_t>(frame.width) * offset[static_cast<size_t>(i)], count, ncclUint32, i,
                                            g_frame.comms[0], b0->stream));
         }
         AEHIP_RCCL_CHECK(api, api.GroupEnd());
@@ -1611,7 +1641,7 @@ extern "C" int aehip_trace_frame(int n_devices, const aehip_scene *scene, const 
             aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
             const size_t bytes = static_cast<size_t>(frame.width) * b->vc.row_count * sizeof(uint32_t);
             AEHIP_CHECK(hipSetDevice(b->device));
-            AEHIP_CHECK(hipMemcpyPeerAsync(b0->d_argb + static_cast<size_t>(frame.width) * bounds[static_cast<size_t>(i)], b0->device,
+            AEHIP_CHECK(hipMemcpyPeerAsync(b0->d_argb + static_cast<size_t>(frame.width) * offset[static_cast<size_t>(i)], b0->device,
                                            b->d_argb, b->device, bytes, b->stream));
         }
     }
@@ -1621,12 +1651,22 @@ extern "C" int aehip_trace_frame(int n_devices, const aehip_scene *scene, const 
         AEHIP_CHECK(hipStreamSynchronize(b->stream));
     }
 
-    // frame -> pinned staging -> caller's buffer
+    // bands -> pinned staging
     AEHIP_CHECK(hipSetDevice(b0->device));
     AEHIP_CHECK(hipMemcpyAsync(b0->h_staging, b0->d_argb, frame_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, b0->stream));
     AEHIP_CHECK(hipEventRecord(b0->ev_copy, b0->stream));
     AEHIP_CHECK(hipStreamSynchronize(b0->stream));
-    std::memcpy(framebuffer, b0->h_staging, frame_pixels * sizeof(uint32_t));
+    // pinned staging (band order) -> caller's buffer (image order), one copy per tile
+    for(int i = 0; i < n; i++) {
+        const uint32_t rows = band_rows[static_cast<size_t>(i)];
+        for(uint32_t j = 0; j < rows; j += T) {
+            const uint32_t tile = static_cast<uint32_t>(i) + (j / T) * static_cast<uint32_t>(n);
+            const uint32_t count = rows - j < T ? rows - j : T;
+            std::memcpy(framebuffer + static_cast<size_t>(frame.width) * tile * T,
+                        b0->h_staging + static_cast<size_t>(frame.width) * (offset[static_cast<size_t>(i)] + j),
+                        static_cast<size_t>(frame.width) * count * sizeof(uint32_t));
+        }
+    }
 
     if(stats_out) {
         aehip_stats total{};

@@ -1,9 +1,14 @@
-"""Row-band sharding of one image across ranks, and the gather of rendered bands to rank 0.
+"""Sharding of one image across ranks by rows, and the gather of rendered bands to rank 0.
 
 Pixels are independent (the reference already renders 4x4 tiles independently,
 src/software_raytracer.cpp:205-240), so a frame shards by rows with no exchange while
 rendering; the only collective is the final gather of packed 0xAARRGGBB bands.  One process per
 GPU, torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
+
+Rows cost very different amounts (a row of sky against a row across the sphere), so a rank's
+band is not a contiguous block but row tiles dealt round-robin: tile k (rows k*T .. k*T+T-1)
+belongs to rank k mod N.  Every rank then renders the same mix of rows.  T defaults to 4, the
+height of the reference's tiles (src/raytracer.h:28) and of the strip one wavefront renders.
 """
 from __future__ import annotations
 
@@ -12,7 +17,7 @@ import torch.distributed as dist
 
 
 def band_bounds(height: int, world: int) -> list[int]:
-    """world+1 row indices; rank r renders rows [b[r], b[r+1]).  Bands differ by at most one row."""
+    """Contiguous split: world+1 row indices; band r = rows [b[r], b[r+1]).  Sizes differ by at most one row."""
     return [height * r // world for r in range(world + 1)]
 
 
@@ -21,39 +26,73 @@ def band_of(height: int, world: int, rank: int) -> tuple[int, int]:
     return b[rank], b[rank + 1] - b[rank]
 
 
+def tiled_band(height: int, world: int, rank: int, tile_rows: int) -> dict:
+    """The band of `rank` when tiles of tile_rows rows are dealt round-robin to `world` ranks, as
+    the aehip_params fields that describe it (row_begin, row_count, tile_rows, tile_stride).
+    tile_rows 0, or a single rank, gives the contiguous split of band_bounds."""
+    if tile_rows == 0 or world == 1:
+        r0, rows = band_of(height, world, rank)
+        return dict(row_begin=r0, row_count=rows, tile_rows=0, tile_stride=0)
+    stride = tile_rows * world
+    span = max(0, height - rank * tile_rows)
+    rows = span // stride * tile_rows + min(span % stride, tile_rows)
+    return dict(row_begin=rank * tile_rows, row_count=rows, tile_rows=tile_rows, tile_stride=stride)
+
+
+def band_image_rows(band: dict) -> list[int]:
+    """Image row of every band row, in band order."""
+    r0, n, t, s = band["row_begin"], band["row_count"], band["tile_rows"], band["tile_stride"]
+    if t == 0:
+        return list(range(r0, r0 + n))
+    return [r0 + (j // t) * s + j % t for j in range(n)]
+
+
 class BandGather:
     """Preallocated gather of per-rank bands into a full image on rank 0.
 
     The collective is dist.gather on equally sized (padded) int32 tensors: rank 0 receives from
-    every peer over its direct xGMI links at once; payload is 4 bytes per pixel.
+    every peer over its direct xGMI links at once; payload is 4 bytes per pixel.  Bands arrive in
+    band order; one row-gather kernel on rank 0 puts the rows in image order (contiguous equal
+    bands are received straight into the image instead).
 
     Two local band buffers alternate so that the gather of frame i (on the collective's own
     stream) overlaps the render of frame i+1 (on the compute stream): `begin(i)` returns the
     buffer to render frame i into, `submit(i)` starts its gather without waiting, `finish()`
-    waits for everything submitted.  `gather()` is the simple blocking form on buffer 0."""
+    waits for everything submitted.  `gather()` is the simple blocking form on buffer 0.
 
-    def __init__(self, width: int, height: int, device: torch.device, dst: int = 0):
+    `band` holds the aehip_params fields of this rank's band (pass as **band to setup())."""
+
+    def __init__(self, width: int, height: int, device: torch.device, dst: int = 0, tile_rows: int = 4):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.dst = dst
         self.width, self.height = width, height
-        self.bounds = band_bounds(height, self.world)
-        self.max_rows = max(self.bounds[r + 1] - self.bounds[r] for r in range(self.world))
-        self.row_begin, self.rows = self.bounds[self.rank], self.bounds[self.rank + 1] - self.bounds[self.rank]
+        self.bands = [tiled_band(height, self.world, r, tile_rows) for r in range(self.world)]
+        self.band = self.bands[self.rank]
+        self.row_begin, self.rows = self.band["row_begin"], self.band["row_count"]
+        self.max_rows = max(b["row_count"] for b in self.bands)
+        self.tiled = self.band["tile_rows"] != 0
         # local band buffers are padded to max_rows so every rank contributes the same shape
         self.locals = [torch.zeros((self.max_rows, width), dtype=torch.int32, device=device) for _ in range(2)]
         self.local = self.locals[0]
-        self.even = all(self.bounds[r + 1] - self.bounds[r] == self.max_rows for r in range(self.world))
+        self.even = all(b["row_count"] == self.max_rows for b in self.bands)
+        self.parts = None
+        self.image = None
+        self._row_source = None
         if self.rank == dst:
             self.image = torch.zeros((height, width), dtype=torch.int32, device=device)
-            if self.even:
-                # equal bands: receive straight into the rows of the final image, no assembly copy
-                self.parts = [self.image[self.bounds[r]:self.bounds[r + 1]] for r in range(self.world)]
+            if self.even and not self.tiled:
+                # equal contiguous bands: receive straight into the rows of the final image
+                self.parts = [self.image[b["row_begin"]:b["row_begin"] + b["row_count"]] for b in self.bands]
             else:
-                self.parts = [torch.zeros((self.max_rows, width), dtype=torch.int32, device=device) for _ in range(self.world)]
-        else:
-            self.parts = None
-            self.image = None
+                self._recv = torch.zeros((self.world, self.max_rows, width), dtype=torch.int32, device=device)
+                self.parts = [self._recv[r] for r in range(self.world)]
+                # image row y comes from row _row_source[y] of the stacked received bands
+                src = torch.zeros(height, dtype=torch.int64)
+                for r, b in enumerate(self.bands):
+                    rows = band_image_rows(b)
+                    src[torch.tensor(rows, dtype=torch.int64)] = torch.arange(len(rows), dtype=torch.int64) + r * self.max_rows
+                self._row_source = src.to(device)
         self._pending = [None, None]
 
     # ------------------------------------------------------------------ blocking form
@@ -68,31 +107,30 @@ class BandGather:
     def begin(self, frame: int) -> torch.Tensor:
         """Buffer to render `frame` into.  Waits (stream-side) for the gather that last read it."""
         slot = frame & 1
-        if self._pending[slot] is not None:
-            self._pending[slot].wait()
-            self._pending[slot] = None
+        self._complete(slot)
         return self.locals[slot]
 
     def submit(self, frame: int) -> None:
         """Starts the gather of the band rendered into begin(frame)'s buffer and returns at once.
         At most one gather is in flight: the previous frame's gather, which had that frame's
-        successor render to hide behind, is completed first, so frames land in the destination
-        image in order on any backend."""
+        successor render to hide behind, is completed (and its rows put in image order) first, so
+        frames land in the destination image in order on any backend."""
         slot = frame & 1
-        other = slot ^ 1
-        if self._pending[other] is not None:
-            self._pending[other].wait()
-            self._pending[other] = None
+        self._complete(slot ^ 1)
         self._pending[slot] = self._start(slot, async_op=True)
 
     def finish(self) -> torch.Tensor | None:
         for slot in (0, 1):
-            if self._pending[slot] is not None:
-                self._pending[slot].wait()
-                self._pending[slot] = None
-        return self._assemble()
+            self._complete(slot)
+        return self.image if self.rank == self.dst else None
 
     # ------------------------------------------------------------------ internals
+
+    def _complete(self, slot: int) -> None:
+        if self._pending[slot] is not None:
+            self._pending[slot].wait()
+            self._pending[slot] = None
+            self._assemble()
 
     def _start(self, slot: int, async_op: bool):
         src = self.locals[slot]
@@ -104,9 +142,6 @@ class BandGather:
     def _assemble(self) -> torch.Tensor | None:
         if self.rank != self.dst:
             return None
-        if self.world == 1 or self.even:
-            return self.image
-        for r in range(self.world):
-            r0, r1 = self.bounds[r], self.bounds[r + 1]
-            self.image[r0:r1].copy_(self.parts[r][: r1 - r0])
+        if self._row_source is not None and self.world > 1:
+            torch.index_select(self._recv.view(self.world * self.max_rows, self.width), 0, self._row_source, out=self.image)
         return self.image

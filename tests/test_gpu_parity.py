@@ -319,6 +319,87 @@ def test_trace_frame_rejects_more_bands_than_rows():
         rt.trace_frame(9, 64, 8, pass_=rt.PASS_PRIMARY)
 
 
+@pytest.mark.parametrize("tile_rows", [1, 4, 7, 16, 64])
+def test_trace_frame_is_independent_of_the_tile_height(tile_rows):
+    sph = scenes.showcase_scene()
+    whole, _ = rt.render(130, 75, spp=3, max_depth=6, seed=9, jitter=True, spheres=sph)
+    for bands in (2, 3):
+        if bands > -(-75 // tile_rows):
+            continue
+        split, st = rt.trace_frame(bands, 130, 75, spp=3, max_depth=6, seed=9, jitter=True, spheres=sph, tile_rows=tile_rows)
+        np.testing.assert_array_equal(split, whole)
+    # a sub-range of rows, cut into tiles relative to its first row
+    if tile_rows >= 41:
+        with pytest.raises(rt.HipRaytracerError):        # one tile cannot feed two devices
+            rt.trace_frame(2, 130, 75, tile_rows=tile_rows, row_begin=10, row_count=41)
+        return
+    part, _ = rt.trace_frame(2, 130, 75, spp=3, max_depth=6, seed=9, jitter=True, spheres=sph, tile_rows=tile_rows,
+                             row_begin=10, row_count=41)
+    np.testing.assert_array_equal(part, whole[10:51])
+
+
+# ------------------------------------------------------------------ row tiles dealt round-robin
+
+def render_tiled(width, height, world, tile_rows, **kw):
+    """Every rank's band through setup()/trace() with the tile fields, rows put back in image order."""
+    from raytracer_amd.sharding import band_image_rows, tiled_band
+    image = np.zeros((height, width), dtype=np.uint32)
+    filled = np.zeros(height, dtype=np.int32)
+    for rank in range(world):
+        band = tiled_band(height, world, rank, tile_rows)
+        rows = band_image_rows(band)
+        # row_count 0 lets the library derive the band's row count itself
+        part, _ = rt.render(width, height, row_begin=band["row_begin"], row_count=0 if rank % 2 else band["row_count"],
+                            tile_rows=band["tile_rows"], tile_stride=band["tile_stride"], **kw)
+        assert part.shape[0] == len(rows)
+        image[rows] = part
+        filled[rows] += 1
+    assert (filled == 1).all()
+    return image
+
+
+@pytest.mark.parametrize("gpus", [2, 4, 8])
+def test_tiled_bands_reassemble_the_4k_reference_image(gpus):
+    """The split bench.py uses on 2/4/8 GPUs: tiles of 4 rows dealt round-robin."""
+    w, h = 3840, 2160
+    want = next(e["sha256"] for e in META["images"] if (e["width"], e["height"]) == (w, h))
+    assert sha(render_tiled(w, h, gpus, 4, pass_=rt.PASS_PRIMARY)) == want
+    assert sha(render_tiled(w, h, gpus, 4, spp=1, max_depth=8, pass_=rt.PASS_PATH)) == want
+
+
+@pytest.mark.parametrize("world,tile_rows,size", [(2, 4, (128, 72)), (3, 5, (130, 75)), (4, 16, (100, 200)), (3, 1, (33, 47)),
+                                                   (2, 1, (255, 3))])
+def test_tiled_bands_equal_the_whole_image(world, tile_rows, size):
+    w, h = size
+    sph = scenes.showcase_scene()
+    kw = dict(spp=4, max_depth=6, seed=9, jitter=True, spheres=sph)
+    whole, _ = rt.render(w, h, **kw)
+    np.testing.assert_array_equal(render_tiled(w, h, world, tile_rows, **kw), whole)            # exact, per-lane pass
+    # camera pass (terminal-only scene), both builds
+    for fast in (False, True):
+        whole_d, _ = rt.render(w, h, spp=8, max_depth=8, seed=3, jitter=True, fast=fast)
+        np.testing.assert_array_equal(render_tiled(w, h, world, tile_rows, spp=8, max_depth=8, seed=3, jitter=True, fast=fast), whole_d)
+    # fast build, pooled pass (>= 16 spheres): the order in which a pixel's samples are added may
+    # differ between launches of different shape, so one code of slack
+    many = scenes.divergence_scene()
+    whole_f, _ = rt.render(w, h, spp=4, max_depth=6, seed=9, jitter=True, fast=True, spheres=many)
+    tiled_f = render_tiled(w, h, world, tile_rows, spp=4, max_depth=6, seed=9, jitter=True, fast=True, spheres=many)
+    assert np.abs(channels(tiled_f) - channels(whole_f)).max() <= 1
+
+
+def test_setup_rejects_bad_tile_requests():
+    back = rt.HipRaytracer(None)
+    try:
+        assert not back.setup(64, 64, tile_rows=4, tile_stride=3)                       # tiles would overlap
+        assert "tile_stride" in back.last_error()
+        assert not back.setup(64, 64, row_begin=0, row_count=33, tile_rows=4, tile_stride=8)    # only 32 such rows
+        assert back.setup(64, 64, row_begin=0, row_count=32, tile_rows=4, tile_stride=8)
+        assert back.setup(64, 62, row_begin=4, row_count=0, tile_rows=4, tile_stride=8) and back.rows == 30   # last tile cut to 2 rows
+        assert not back.setup(64, 64, row_begin=64, tile_rows=4, tile_stride=8)
+    finally:
+        back.close()
+
+
 # ------------------------------------------------------------------ ragged and tiny images
 
 @pytest.mark.parametrize("size", [(1, 1), (3, 2), (17, 5), (64, 1), (1, 70), (33, 47), (255, 3)])

@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle
-from raytracer_amd.sharding import BandGather, band_bounds, band_of
+from raytracer_amd.sharding import BandGather, band_bounds, band_image_rows, band_of, tiled_band
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 META = json.load(open(os.path.join(GOLDEN, "reference_images.json")))
@@ -35,12 +35,37 @@ def test_band_bounds_cover_the_image_without_overlap():
             assert band_of(height, world, world - 1) == (b[-2], sizes[-1])
 
 
-def _worker(rank, world, port, width, height, out_path):
+def test_tiled_bands_cover_the_image_without_overlap():
+    for height in (4, 8, 72, 270, 1080, 2160, 2161, 2163):
+        for world in (1, 2, 3, 4, 7, 8):
+            for tile_rows in (0, 1, 4, 5, 16):
+                if tile_rows and world > -(-height // tile_rows):
+                    continue                      # more ranks than tiles
+                bands = [tiled_band(height, world, r, tile_rows) for r in range(world)]
+                rows = [y for b in bands for y in band_image_rows(b)]
+                assert sorted(rows) == list(range(height)), (height, world, tile_rows)
+                sizes = [b["row_count"] for b in bands]
+                assert max(sizes) - min(sizes) <= max(1, tile_rows)
+                for b in bands:                   # the same count the library derives for row_count 0
+                    import raytracer_amd as rt
+                    if b["tile_rows"] == 0:
+                        continue
+                    assert rt.band_row_count(height, b["row_begin"], b["tile_rows"], b["tile_stride"]) == b["row_count"]
+
+
+def _oracle_band(width, height, g):
+    """The rank's band cut out of the oracle's image, in band order."""
+    full = oracle.trace_primary(width, height)
+    return np.ascontiguousarray(full[band_image_rows(g.band)])
+
+
+def _worker(rank, world, port, width, height, out_path, tile_rows):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        g = BandGather(width, height, torch.device("cpu"))
-        band = oracle.trace_primary(width, height, row_begin=g.row_begin, row_count=g.rows)
+        g = BandGather(width, height, torch.device("cpu"), tile_rows=tile_rows)
+        band = _oracle_band(width, height, g)
+        assert band.shape[0] == g.rows
         g.local[: g.rows].copy_(torch.from_numpy(band.view(np.int32)))
         image = g.gather()
         if rank == 0:
@@ -51,11 +76,12 @@ def _worker(rank, world, port, width, height, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,size", [(2, (128, 72)), (3, (100, 200)), (4, (512, 64))])
-def test_gather_of_bands_rebuilds_reference_image(tmp_path, world, size):
+@pytest.mark.parametrize("world,size,tile_rows", [(2, (128, 72), 4), (3, (100, 200), 4), (4, (512, 64), 4),
+                                                  (3, (100, 200), 16), (2, (128, 72), 0), (3, (100, 200), 0)])
+def test_gather_of_bands_rebuilds_reference_image(tmp_path, world, size, tile_rows):
     width, height = size
     out = str(tmp_path / "image.npy")
-    mp.spawn(_worker, args=(world, free_port(), width, height, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, free_port(), width, height, out, tile_rows), nprocs=world, join=True)
     image = np.load(out)
     want = next(e["sha256"] for e in META["images"] if (e["width"], e["height"]) == (width, height))
     assert hashlib.sha256(image.tobytes()).hexdigest() == want
@@ -66,7 +92,7 @@ def _worker_overlapped(rank, world, port, width, height, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         g = BandGather(width, height, torch.device("cpu"))
-        band = torch.from_numpy(oracle.trace_primary(width, height, row_begin=g.row_begin, row_count=g.rows).view(np.int32))
+        band = torch.from_numpy(_oracle_band(width, height, g).view(np.int32))
         frames = 5
         for i in range(frames):
             buf = g.begin(i)
