@@ -142,9 +142,18 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
+    # everything runs on one side stream: the library treats the null stream as "use your own and
+    # wait", and launches are to queue back to back without the host in between
+    if share:
+        stream = None                   # gloo's device-tensor path is slow off the default stream
+    else:
+        side = torch.cuda.Stream(device=device)
+        torch.cuda.set_stream(side)
+        stream = side.cuda_stream
     gather = BandGather(WIDTH, HEIGHT, device)
     overlap = not share                 # gloo's asynchronous gather of device tensors does not complete here
-    stream = torch.cuda.current_stream().cuda_stream
+
+    verified = {}
 
     def timed_run(mode, steps, warmup):
         """K steps of render-band + gather; returns (elapsed_s max over ranks, kernel_s max over ranks, stats)."""
@@ -181,6 +190,21 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         st = back.stats()
         back.close()
+        # outside the timed region: the gathered frame must be the frame one GPU renders alone
+        # (sample keys depend on the absolute pixel only, so the split cannot change a bit)
+        if rank == 0:
+            whole = rt.HipRaytracer(None, device=dev_index)
+            whole.setup(WIDTH, HEIGHT, spp=args.spp, max_depth=args.depth, seed=1, flags=flags, pass_=rt.PASS_PATH)
+            ref = torch.empty((HEIGHT, WIDTH), dtype=torch.int32, device=device)
+            torch.cuda.synchronize()
+            whole.trace_device(ref.data_ptr(), None, stream)
+            torch.cuda.synchronize()
+            whole.close()
+            verified[mode] = bool(torch.equal(ref, gather.image))
+            if not verified[mode]:
+                ne = ref != gather.image
+                idx = ne.nonzero()[:6].tolist()
+                print("MISMATCH", mode, int(ne.sum()), idx, [(hex(ref[y, x].item() & 0xffffffff), hex(gather.image[y, x].item() & 0xffffffff)) for y, x in idx], file=sys.stderr, flush=True)
         return float(t[0]), float(t[1]), st
 
     other = "exact" if args.mode == "fast" else "fast"
@@ -212,6 +236,7 @@ def main():
                 "rays_per_path": 1,
             },
             "kernel_ms": kernel_s * 1e3,
+            "gathered_frame_equals_single_gpu_frame": verified,
             "rays_per_s": paths_total / (elapsed / args.steps),
             "roofline": {
                 "bound": "valu_fp32",

@@ -78,12 +78,16 @@ typedef struct aehip_scene {
     const aehip_sphere *spheres;   /* host memory, copied by setup */
 } aehip_scene;
 
+#define AEHIP_SAMPLE_BLOCK 64u
+
 typedef struct aehip_params {
     uint32_t width, height;         /* what raytracer::get_resolution() returns (src/raytracer.cpp:18-34) */
     uint32_t row_begin, row_count;  /* band of image rows this backend renders; row_count 0 = every row
                                        of the band below `height`.  Outputs hold the band's row_count
                                        rows densely, band row 0 = image row row_begin. */
-    uint32_t spp;                   /* samples per pixel, >= 1 */
+    uint32_t spp;                   /* samples per pixel, >= 1.  A pixel's samples are summed in blocks
+                                       of AEHIP_SAMPLE_BLOCK: sample order inside a block, block sums
+                                       in block order (blocks are independent work for the GPU). */
     uint32_t max_depth;             /* ray segments per path, >= 1 */
     uint32_t seed;
     uint32_t flags;                 /* AEHIP_FLAG_* */

@@ -377,11 +377,18 @@ static void trace_rows(const orc_scene *scene, const orc_params *p, const view_t
     for(uint32_t row = row0; row < row1; row++) {
         const uint32_t y = p->row_begin + row;
         for(uint32_t x = 0; x < p->width; x++) {
+            /* samples accumulate in blocks of ORC_SAMPLE_BLOCK: index order inside a block, block
+               sums in block order (blocks are independent, so a GPU can spread them over waves) */
             float sum[3] = {0.0f, 0.0f, 0.0f};
-            for(uint32_t s = 0; s < p->spp; s++) {          /* samples accumulate in index order */
-                float L[3];
-                trace_one_path(scene, v, p, x, y, s, L, rays);
-                sum[0] += L[0]; sum[1] += L[1]; sum[2] += L[2];
+            for(uint32_t s0 = 0; s0 < p->spp; s0 += ORC_SAMPLE_BLOCK) {
+                const uint32_t s1 = p->spp - s0 < ORC_SAMPLE_BLOCK ? p->spp : s0 + ORC_SAMPLE_BLOCK;
+                float block[3] = {0.0f, 0.0f, 0.0f};
+                for(uint32_t s = s0; s < s1; s++) {
+                    float L[3];
+                    trace_one_path(scene, v, p, x, y, s, L, rays);
+                    block[0] += L[0]; block[1] += L[1]; block[2] += L[2];
+                }
+                sum[0] += block[0]; sum[1] += block[1]; sum[2] += block[2];
             }
             const float n = (float)p->spp;
             const float r = clamp01(sum[0] / n), g = clamp01(sum[1] / n), b = clamp01(sum[2] / n);

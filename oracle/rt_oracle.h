@@ -26,6 +26,7 @@ extern "C" {
 
 enum { ORC_MAT_NORMAL = 0, ORC_MAT_LAMBERT = 1, ORC_MAT_METAL = 2, ORC_MAT_DIELECTRIC = 3 };
 enum { ORC_FLAG_JITTER = 1u };
+enum { ORC_SAMPLE_BLOCK = 64 };     /* a pixel's samples are summed in blocks of this many */
 
 /* 48 bytes; same field order as aehip_sphere so tests can hand one numpy array to both sides */
 typedef struct orc_sphere {

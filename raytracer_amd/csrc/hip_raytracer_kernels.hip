@@ -596,7 +596,8 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
         __syncthreads();
     }
 
-    f3 sum = {0.0f, 0.0f, 0.0f};
+    f3 sum = {0.0f, 0.0f, 0.0f};      // block sums in block order
+    f3 block = {0.0f, 0.0f, 0.0f};    // the current block's samples in sample order
     uint32_t sample = 0;
     uint32_t nrays = 0;
     uint32_t iterations = 0;        // segment iterations this wave executed (same value in every lane)
@@ -650,10 +651,16 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
             nrays++;
             f3 L;
             if(shade_segment<EXACT>(vc, y, hit, closest, geom, matl, kind, ps, L)) {
-                sum.x += L.x;
-                sum.y += L.y;
-                sum.z += L.z;
+                block.x += L.x;
+                block.y += L.y;
+                block.z += L.z;
                 sample++;
+                if((sample & (AEHIP_SAMPLE_BLOCK - 1u)) == 0u || sample >= vc.spp) {    // block complete
+                    sum.x += block.x;
+                    sum.y += block.y;
+                    sum.z += block.z;
+                    block = f3{0.0f, 0.0f, 0.0f};
+                }
                 if(sample >= vc.spp) {
                     alive = false;
                     tracing = false;
@@ -818,23 +825,41 @@ __global__ __launch_bounds__(kBlock) void path_pool_kernel(view_consts vc, const
 // (oc = C - camera, c = oc.oc - r*r) are computed once per workgroup, and the sample key is the
 // per-pixel term plus the tabulated per-sample term, fetched through the scalar cache one
 // iteration ahead.  Results are the same bits as path_kernel's (exact build) for such scenes.
+//
+// Work split: a wave renders a 16x4 pixel strip, one pixel per lane.  The samples of a pixel are
+// summed in blocks of AEHIP_SAMPLE_BLOCK, and blocks are independent, so 2^split_log2 waves of
+// the workgroup share a strip and take its blocks in turn.  Waves are that much shorter and that
+// many more, which shortens the launch's tail (the time the last waves run on a chip that is
+// emptying) in proportion -- a third of the run time of a 4K band on one of 8 GPUs otherwise.
+// The exact build adds block sums in block order: the waves of a strip meet after every round of
+// blocks and each adds the round's sums to its copy of the total.  The fast build keeps one sum
+// per wave and adds them once at the end.
 // ------------------------------------------------------------------------------------------
 
 template <bool EXACT, bool ONE, bool FOLD>
-__global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_consts cc, const float4 *__restrict__ geom,
+__global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_consts cc, uint32_t split_log2,
+                                                        const float4 *__restrict__ geom,
                                                         const uint32_t *__restrict__ sample_terms,
                                                         uint32_t *__restrict__ argb, float4 *__restrict__ rgba,
                                                         unsigned long long *ray_counter) {
+    constexpr uint32_t kWaves = kBlock / 64;
     __shared__ float4 s_occ[ONE ? 1 : kLdsSpheres];     // oc.xyz, c
     __shared__ float4 s_ctr[ONE ? 1 : kLdsSpheres];     // centre.xyz, oc.oc + r*r
+    __shared__ float s_part[EXACT ? 2 : 1][kWaves][3][64];      // per-wave sums handed to the strip's other waves
+    __shared__ uint32_t s_hits[EXACT ? 1 : kWaves][64];
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t x = blockIdx.x * kTileW + (tid & (kTileW - 1));
-    const uint32_t row = blockIdx.y * kTileH + (tid / kTileW);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+    const uint32_t split = 1u << split_log2;                    // waves per strip
+    const uint32_t strip = wave >> split_log2;                  // strip of the workgroup
+    const uint32_t part = wave & (split - 1u);                  // this wave's place among the strip's waves
+    const uint32_t x = blockIdx.x * kTileW + (lane & 15u);
+    const uint32_t row = (blockIdx.y * (kWaves >> split_log2) + strip) * 4u + (lane >> 4);
     const uint32_t y = image_row(vc, row);
     const bool valid = (x < vc.width) && (row < vc.row_count);
     const f3 cam = {vc.cam[0], vc.cam[1], vc.cam[2]};
     const uint32_t n_spheres = ONE ? 1u : vc.n_spheres;
+    const uint32_t nblocks = (vc.spp + AEHIP_SAMPLE_BLOCK - 1u) / AEHIP_SAMPLE_BLOCK;
 
     if constexpr(!ONE) {
         for(uint32_t i = tid; i < n_spheres; i += kBlock) {
@@ -847,95 +872,176 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
         __syncthreads();
     }
 
-    if(valid) {
-        const f3 bg = row_background<EXACT>(vc, y);
-        const uint32_t pix_term = pixel_term(vc.seed_hash, y * vc.width + x);
-        // sample position = base + draw * scale: (2^-16, +0) with jitter, (0, +0.5) without.
-        // Both products are exact, so the fused form rounds once, like multiply-then-add.
-        const bool jitter = (vc.flags & AEHIP_FLAG_JITTER) != 0;
-        const float jscale = jitter ? (1.0f / 65536.0f) : 0.0f;
-        const float xb = static_cast<float>(x) + (jitter ? 0.0f : 0.5f);
-        const float yb = static_cast<float>(y) + (jitter ? 0.0f : 0.5f);
-        const float dz = 0.0f - cam.z;
+    const f3 bg = row_background<EXACT>(vc, y);
+    const uint32_t pix_term = pixel_term(vc.seed_hash, y * vc.width + x);
+    // sample position = base + draw * scale: (2^-16, +0) with jitter, (0, +0.5) without.
+    // Both products are exact, so the fused form rounds once, like multiply-then-add.
+    const bool jitter = (vc.flags & AEHIP_FLAG_JITTER) != 0;
+    const float jscale = jitter ? (1.0f / 65536.0f) : 0.0f;
+    const float xb = static_cast<float>(x) + (jitter ? 0.0f : 0.5f);
+    const float yb = static_cast<float>(y) + (jitter ? 0.0f : 0.5f);
+    const float dz = 0.0f - cam.z;
+    // per-pixel terms of the sample position folded into one fma per coordinate
+    const float ux0 = __builtin_fmaf(xb, vc.psx, -(vc.vw_half + cam.x));
+    const float uy0 = __builtin_fmaf(yb, vc.psy, -(vc.vh_half + cam.y));
+    const float sx = jscale * vc.psx, sy = jscale * vc.psy;
+    const float dz2 = dz * dz;
 
-        f3 sum = {0.0f, 0.0f, 0.0f};
+    f3 sum = {0.0f, 0.0f, 0.0f};
+    uint32_t my_samples = 0;            // samples this wave traces per pixel (wave-uniform)
 
-        if constexpr(EXACT) {
-            // screening ray with the per-pixel terms folded into one fma per coordinate (see below)
-            constexpr bool fold = FOLD;
-            const float ux0 = __builtin_fmaf(xb, vc.psx, -(vc.vw_half + cam.x));
-            const float uy0 = __builtin_fmaf(yb, vc.psy, -(vc.vh_half + cam.y));
-            const float sx = jscale * vc.psx, sy = jscale * vc.psy;
-            const float dz2 = dz * dz;
+    if constexpr(EXACT) {
+        // the sample's ray exactly as the reference builds it (src/software_raytracer.cpp:218-221)
+        auto exact_draw = [&](uint32_t key) {
+            const float px = __builtin_fmaf(static_cast<float>(key >> 16), jscale, xb);
+            const float py = __builtin_fmaf(static_cast<float>(key & 0xffffu), jscale, yb);
+            const float uvx = px * vc.psx - vc.vw_half;
+            const float uvy = py * vc.psy - vc.vh_half;
+            return f3{uvx - cam.x, uvy - cam.y, dz};
+        };
 
-            // the sample's ray exactly as the reference builds it (src/software_raytracer.cpp:218-221)
-            auto exact_draw = [&](uint32_t key) {
-                const float px = __builtin_fmaf(static_cast<float>(key >> 16), jscale, xb);
-                const float py = __builtin_fmaf(static_cast<float>(key & 0xffffu), jscale, yb);
-                const float uvx = px * vc.psx - vc.vw_half;
-                const float uvy = py * vc.psy - vc.vh_half;
-                return f3{uvx - cam.x, uvy - cam.y, dz};
-            };
+        for(uint32_t first = 0; first < nblocks; first += split) {      // a round: `split` consecutive blocks
+            const uint32_t blk = first + part;
+            f3 block = {0.0f, 0.0f, 0.0f};
+            if(blk < nblocks) {
+                const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
+                const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
+                my_samples += s1 - s0;
+                uint32_t term = sample_terms[s0];
+                if(valid) {
+                    for(uint32_t sample = s0; sample < s1; sample++) {
+                        const uint32_t key = pix_term + term;
+                        term = sample_terms[sample + 1];        // next sample's term (table has one spare entry)
 
-            uint32_t term = sample_terms[0];
-            for(uint32_t sample = 0; sample < vc.spp; sample++) {
-                const uint32_t key = pix_term + term;
-                term = sample_terms[sample + 1];        // next sample's term (table has one spare entry)
+                        // Conservative miss test on the unnormalised ray in fused arithmetic.  With
+                        // h = draw.oc and dd = draw.draw the reference's discriminant has the sign of
+                        // h*h - dd*c.  Both evaluations are within about a dozen unit roundoffs of
+                        // h*h + dd*(oc.oc + r*r), so a value below -kScreenMargin of that magnitude is
+                        // negative in the exact evaluation as well, and the sample takes the row
+                        // background whatever its direction is.  Everything else runs the exact
+                        // arithmetic below.  Where the camera is not close to the viewport plane (host
+                        // check, kFlagFoldScreen) the screening ray comes from two fmas instead of the
+                        // reference's six operations: it differs from the exact ray by a few ulps of the
+                        // viewport extent, which moves the screening value by under 6e-6 of the
+                        // magnitude -- inside the margin with room to spare.
+                        f3 draw = {0.0f, 0.0f, dz};
+                        float rx, ry;
+                        if constexpr(FOLD) {
+                            rx = __builtin_fmaf(static_cast<float>(key >> 16), sx, ux0);
+                            ry = __builtin_fmaf(static_cast<float>(key & 0xffffu), sy, uy0);
+                        } else {
+                            draw = exact_draw(key);
+                            rx = draw.x;
+                            ry = draw.y;
+                        }
+                        const float dd = __builtin_fmaf(ry, ry, __builtin_fmaf(rx, rx, dz2));
+                        bool maybe = false;
+                        for(uint32_t i = 0; i < n_spheres; i++) {
+                            const float4 k = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
+                            const float mag = ONE ? cc.magnitude : s_ctr[i].w;
+                            const float h = __builtin_fmaf(ry, k.y, __builtin_fmaf(rx, k.x, dz * k.z));
+                            const float q = h * h;
+                            const float screen = __builtin_fmaf(kScreenMargin, __builtin_fmaf(dd, mag, q), __builtin_fmaf(-dd, k.w, q));
+                            maybe = maybe || (screen >= 0.0f);
+                        }
+                        if constexpr(FOLD) {
+                            if(maybe) draw = exact_draw(key);
+                        }
 
-                // Conservative miss test on the unnormalised ray in fused arithmetic.  With
-                // h = draw.oc and dd = draw.draw the reference's discriminant has the sign of
-                // h*h - dd*c.  Both evaluations are within about a dozen unit roundoffs of
-                // h*h + dd*(oc.oc + r*r), so a value below -kScreenMargin of that magnitude is
-                // negative in the exact evaluation as well, and the sample takes the row
-                // background whatever its direction is.  Everything else runs the exact
-                // arithmetic below.  Where the camera is not close to the viewport plane (host
-                // check, kFlagFoldScreen) the screening ray comes from two fmas instead of the
-                // reference's six operations: it differs from the exact ray by a few ulps of the
-                // viewport extent, which moves the screening value by under 6e-6 of the
-                // magnitude -- inside the margin with room to spare.
-                f3 draw = {0.0f, 0.0f, dz};
-                float rx, ry;
-                if constexpr(fold) {
-                    rx = __builtin_fmaf(static_cast<float>(key >> 16), sx, ux0);
-                    ry = __builtin_fmaf(static_cast<float>(key & 0xffffu), sy, uy0);
-                } else {
-                    draw = exact_draw(key);
-                    rx = draw.x;
-                    ry = draw.y;
+                        f3 L = bg;
+                        if(maybe) {
+                            const f3 d = normalize3<true>(draw);
+                            const float a = dot3<true>(d, d);
+                            const float a4 = 4.0f * a;
+                            const float a2 = 2.0f * a;
+                            float closest = 3.402823466e+38f;
+                            int hit = -1;
+                            for(uint32_t i = 0; i < n_spheres; i++) {
+                                const float4 k = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
+                                const float b = -2.0f * dot3<true>(d, f3{k.x, k.y, k.z});
+                                const float disc = b * b - a4 * k.w;
+                                if(disc >= 0.0f) {
+                                    const float sq = rt_sqrt<true>(disc);
+                                    float t = (-b - sq) / a2;
+                                    bool ok = (t > kTMin) && (t < closest);
+                                    if(!ok) {
+                                        t = (-b + sq) / a2;
+                                        ok = (t > kTMin) && (t < closest);
+                                    }
+                                    if(ok) {
+                                        closest = t;
+                                        hit = static_cast<int>(i);
+                                    }
+                                }
+                            }
+                            if(hit >= 0) {
+                                const f3 ctr = ONE ? f3{cc.center[0], cc.center[1], cc.center[2]}
+                                                   : f3{s_ctr[hit].x, s_ctr[hit].y, s_ctr[hit].z};
+                                const f3 pt = {d.x * closest + cam.x, d.y * closest + cam.y, d.z * closest + cam.z};
+                                const f3 n = normalize3<true>(f3{pt.x - ctr.x, pt.y - ctr.y, pt.z - ctr.z});
+                                L = f3{remap_unit(n.x), remap_unit(n.y), remap_unit(n.z)};      // throughput is 1
+                            }
+                        }
+                        block.x += L.x;
+                        block.y += L.y;
+                        block.z += L.z;
+                    }
                 }
-                const float dd = __builtin_fmaf(ry, ry, __builtin_fmaf(rx, rx, dz2));
-                bool maybe = false;
-                for(uint32_t i = 0; i < n_spheres; i++) {
-                    const float4 k = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
-                    const float mag = ONE ? cc.magnitude : s_ctr[i].w;
-                    const float h = __builtin_fmaf(ry, k.y, __builtin_fmaf(rx, k.x, dz * k.z));
-                    const float q = h * h;
-                    const float screen = __builtin_fmaf(kScreenMargin, __builtin_fmaf(dd, mag, q), __builtin_fmaf(-dd, k.w, q));
-                    maybe = maybe || (screen >= 0.0f);
+            }
+            if(split == 1u) {
+                sum.x += block.x;
+                sum.y += block.y;
+                sum.z += block.z;
+            } else {
+                // hand the block sum to the strip's other waves; every wave adds the round's sums in
+                // block order to its own copy of the total.  Two buffers alternate, so the barrier
+                // of the next round also orders this round's reads before the buffer's next writes.
+                const uint32_t buf = (first >> split_log2) & 1u;
+                s_part[buf][wave][0][lane] = block.x;
+                s_part[buf][wave][1][lane] = block.y;
+                s_part[buf][wave][2][lane] = block.z;
+                __syncthreads();
+                const uint32_t live = min(split, nblocks - first);
+                const uint32_t w0 = strip << split_log2;
+                for(uint32_t p = 0; p < live; p++) {
+                    sum.x += s_part[buf][w0 + p][0][lane];
+                    sum.y += s_part[buf][w0 + p][1][lane];
+                    sum.z += s_part[buf][w0 + p][2][lane];
                 }
-                if constexpr(fold) {
-                    if(maybe) draw = exact_draw(key);
-                }
-
-                f3 L = bg;
-                if(maybe) {
-                    const f3 d = normalize3<true>(draw);
-                    const float a = dot3<true>(d, d);
-                    const float a4 = 4.0f * a;
-                    const float a2 = 2.0f * a;
+            }
+        }
+    } else {
+        // fast build: the ray stays unnormalised (the hit test is scale invariant, t runs
+        // along `draw`); only hits add to the sum, misses are counted and added as
+        // (misses * background); the order of additions is free
+        uint32_t hits = 0;
+        for(uint32_t blk = part; blk < nblocks; blk += split) {
+            const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
+            const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
+            my_samples += s1 - s0;
+            uint32_t term = sample_terms[s0];
+            if(valid) {
+                for(uint32_t sample = s0; sample < s1; sample++) {
+                    const uint32_t key = pix_term + term;
+                    term = sample_terms[sample + 1];        // next sample's term (table has one spare entry)
+                    const float dx = __builtin_fmaf(static_cast<float>(key >> 16), sx, ux0);
+                    const float dy = __builtin_fmaf(static_cast<float>(key & 0xffffu), sy, uy0);
+                    const float dd = __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, dz2));
                     float closest = 3.402823466e+38f;
                     int hit = -1;
                     for(uint32_t i = 0; i < n_spheres; i++) {
                         const float4 k = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
-                        const float b = -2.0f * dot3<true>(d, f3{k.x, k.y, k.z});
-                        const float disc = b * b - a4 * k.w;
+                        const float h = __builtin_fmaf(dy, k.y, __builtin_fmaf(dx, k.x, dz * k.z));
+                        const float disc = __builtin_fmaf(-dd, k.w, h * h);
                         if(disc >= 0.0f) {
-                            const float sq = rt_sqrt<true>(disc);
-                            float t = (-b - sq) / a2;
-                            bool ok = (t > kTMin) && (t < closest);
+                            const float sq = __builtin_amdgcn_sqrtf(disc);
+                            const float inv = __builtin_amdgcn_rcpf(dd);
+                            const float tmin = kTMin * __builtin_amdgcn_rsqf(dd);       // t_min in units of |draw|
+                            float t = (h - sq) * inv;
+                            bool ok = (t > tmin) && (t < closest);
                             if(!ok) {
-                                t = (-b + sq) / a2;
-                                ok = (t > kTMin) && (t < closest);
+                                t = (h + sq) * inv;
+                                ok = (t > tmin) && (t < closest);
                             }
                             if(ok) {
                                 closest = t;
@@ -946,71 +1052,39 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
                     if(hit >= 0) {
                         const f3 ctr = ONE ? f3{cc.center[0], cc.center[1], cc.center[2]}
                                            : f3{s_ctr[hit].x, s_ctr[hit].y, s_ctr[hit].z};
-                        const f3 pt = {d.x * closest + cam.x, d.y * closest + cam.y, d.z * closest + cam.z};
-                        const f3 n = normalize3<true>(f3{pt.x - ctr.x, pt.y - ctr.y, pt.z - ctr.z});
-                        L = f3{remap_unit(n.x), remap_unit(n.y), remap_unit(n.z)};      // throughput is 1
+                        const f3 v = {__builtin_fmaf(dx, closest, cam.x - ctr.x), __builtin_fmaf(dy, closest, cam.y - ctr.y),
+                                      __builtin_fmaf(dz, closest, cam.z - ctr.z)};
+                        const float half_inv = 0.5f * __builtin_amdgcn_rsqf(dot3<false>(v, v));
+                        sum.x += __builtin_fmaf(v.x, half_inv, 0.5f);
+                        sum.y += __builtin_fmaf(v.y, half_inv, 0.5f);
+                        sum.z += __builtin_fmaf(v.z, half_inv, 0.5f);
+                        hits++;
                     }
                 }
-                sum.x += L.x;
-                sum.y += L.y;
-                sum.z += L.z;
             }
-        } else {
-            // fast build: the ray stays unnormalised (the hit test is scale invariant, t runs
-            // along `draw`); per-pixel terms of the sample position are folded into one fma;
-            // only hits add to the sum, misses are counted and added as (misses * background)
-            const float ux0 = __builtin_fmaf(xb, vc.psx, -(vc.vw_half + cam.x));
-            const float uy0 = __builtin_fmaf(yb, vc.psy, -(vc.vh_half + cam.y));
-            const float sx = jscale * vc.psx, sy = jscale * vc.psy;
-            const float dz2 = dz * dz;
-            uint32_t hits = 0;
-            uint32_t term = sample_terms[0];
-            for(uint32_t sample = 0; sample < vc.spp; sample++) {
-                const uint32_t key = pix_term + term;
-                term = sample_terms[sample + 1];        // next sample's term (table has one spare entry)
-                const float dx = __builtin_fmaf(static_cast<float>(key >> 16), sx, ux0);
-                const float dy = __builtin_fmaf(static_cast<float>(key & 0xffffu), sy, uy0);
-                const float dd = __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, dz2));
-                float closest = 3.402823466e+38f;
-                int hit = -1;
-                for(uint32_t i = 0; i < n_spheres; i++) {
-                    const float4 k = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
-                    const float h = __builtin_fmaf(dy, k.y, __builtin_fmaf(dx, k.x, dz * k.z));
-                    const float disc = __builtin_fmaf(-dd, k.w, h * h);
-                    if(disc >= 0.0f) {
-                        const float sq = __builtin_amdgcn_sqrtf(disc);
-                        const float inv = __builtin_amdgcn_rcpf(dd);
-                        const float tmin = kTMin * __builtin_amdgcn_rsqf(dd);       // t_min in units of |draw|
-                        float t = (h - sq) * inv;
-                        bool ok = (t > tmin) && (t < closest);
-                        if(!ok) {
-                            t = (h + sq) * inv;
-                            ok = (t > tmin) && (t < closest);
-                        }
-                        if(ok) {
-                            closest = t;
-                            hit = static_cast<int>(i);
-                        }
-                    }
-                }
-                if(hit >= 0) {
-                    const f3 ctr = ONE ? f3{cc.center[0], cc.center[1], cc.center[2]}
-                                       : f3{s_ctr[hit].x, s_ctr[hit].y, s_ctr[hit].z};
-                    const f3 v = {__builtin_fmaf(dx, closest, cam.x - ctr.x), __builtin_fmaf(dy, closest, cam.y - ctr.y),
-                                  __builtin_fmaf(dz, closest, cam.z - ctr.z)};
-                    const float half_inv = 0.5f * __builtin_amdgcn_rsqf(dot3<false>(v, v));
-                    sum.x += __builtin_fmaf(v.x, half_inv, 0.5f);
-                    sum.y += __builtin_fmaf(v.y, half_inv, 0.5f);
-                    sum.z += __builtin_fmaf(v.z, half_inv, 0.5f);
-                    hits++;
-                }
-            }
-            const float misses = static_cast<float>(vc.spp - hits);
-            sum.x = __builtin_fmaf(misses, bg.x, sum.x);
-            sum.y = __builtin_fmaf(misses, bg.y, sum.y);
-            sum.z = __builtin_fmaf(misses, bg.z, sum.z);
         }
+        if(split > 1u) {
+            s_part[0][wave][0][lane] = sum.x;
+            s_part[0][wave][1][lane] = sum.y;
+            s_part[0][wave][2][lane] = sum.z;
+            s_hits[wave][lane] = hits;
+            __syncthreads();
+            if(part == 0u) {
+                for(uint32_t p = 1; p < split; p++) {
+                    sum.x += s_part[0][wave + p][0][lane];
+                    sum.y += s_part[0][wave + p][1][lane];
+                    sum.z += s_part[0][wave + p][2][lane];
+                    hits += s_hits[wave + p][lane];
+                }
+            }
+        }
+        const float misses = static_cast<float>(vc.spp - hits);
+        sum.x = __builtin_fmaf(misses, bg.x, sum.x);
+        sum.y = __builtin_fmaf(misses, bg.y, sum.y);
+        sum.z = __builtin_fmaf(misses, bg.z, sum.z);
+    }
 
+    if(valid && part == 0u) {
         const float n = static_cast<float>(vc.spp);
         const float r = clamp01(rt_div<EXACT>(sum.x, n));
         const float g = clamp01(rt_div<EXACT>(sum.y, n));
@@ -1021,13 +1095,13 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
     }
 
     if(vc.flags & AEHIP_FLAG_COUNT_RAYS) {
-        uint32_t v = valid ? vc.spp : 0u;
+        uint32_t v = valid ? my_samples : 0u;
         const bool wave_has_work = __any(valid);
 #pragma unroll
         for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if((tid & 63u) == 0) {
+        if(lane == 0) {
             atomicAdd(ray_counter, static_cast<unsigned long long>(v));
-            atomicAdd(ray_counter + 1, wave_has_work ? 64ull * vc.spp : 0ull);
+            atomicAdd(ray_counter + 1, wave_has_work ? 64ull * my_samples : 0ull);
         }
     }
 }
@@ -1107,13 +1181,24 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         else if(vec4) { func = reinterpret_cast<const void *>(primary_kernel<false, true>); hipLaunchKernelGGL((primary_kernel<false, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba); }
         else { func = reinterpret_cast<const void *>(primary_kernel<false, false>); hipLaunchKernelGGL((primary_kernel<false, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba); }
     } else if(b->all_terminal && vc.n_spheres <= static_cast<uint32_t>(kLdsSpheres)) {
-        const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + kTileH - 1) / kTileH);
+        // waves per strip: as many as divide the pixel's sample blocks evenly (or nearly so)
+        const uint32_t nblocks = (vc.spp + AEHIP_SAMPLE_BLOCK - 1u) / AEHIP_SAMPLE_BLOCK;
+        uint32_t split_log2 = 0;
+        for(uint32_t l = 2; l >= 1; l--) {
+            const uint32_t waves = 1u << l;
+            if(nblocks % waves == 0 || nblocks >= 4u * waves) {
+                split_log2 = l;
+                break;
+            }
+        }
+        const uint32_t rows_per_group = static_cast<uint32_t>(kTileH) >> split_log2;
+        const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + rows_per_group - 1) / rows_per_group);
         const bool one = vc.n_spheres == 1;
         const bool fold = (vc.flags & kFlagFoldScreen) != 0;
 #define AEHIP_LAUNCH_CAMERA(E, O, F)                                                                                   \
     do {                                                                                                               \
         func = reinterpret_cast<const void *>(camera_kernel<E, O, F>);                                                 \
-        hipLaunchKernelGGL((camera_kernel<E, O, F>), grid, dim3(kBlock), 0, stream, vc, b->cc, b->d_geom,              \
+        hipLaunchKernelGGL((camera_kernel<E, O, F>), grid, dim3(kBlock), 0, stream, vc, b->cc, split_log2, b->d_geom,  \
                            b->d_sample_terms, argb_dev, rgba, b->d_rays);                                              \
     } while(0)
         if(exact) {
