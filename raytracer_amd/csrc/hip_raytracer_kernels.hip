@@ -246,6 +246,10 @@ struct camera_consts {       // travels as a kernel argument (SGPRs)
     float c;                 // oc.oc - r*r     (src/shapes.cpp:18)
     float center[3];
     float magnitude;         // oc.oc + r*r: size of the terms behind c, for the screening margin
+    // The hit discriminant of an unnormalised ray (u, v, dz) from the camera, h*h - dd*c with
+    // h = (u, v, dz).oc and dd = u*u + v*v + dz*dz, written out as a quadratic in the ray's
+    // viewport offsets: q_uu u*u + q_uv u*v + q_vv v*v + q_u u + q_v v + q_0
+    float q_uu, q_uv, q_vv, q_u, q_v, q_0;
 };
 
 // Relative margin of the exact build's conservative miss tests (see screen_sphere below).
@@ -887,6 +891,34 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
     const float sx = jscale * vc.psx, sy = jscale * vc.psy;
     const float dz2 = dz * dz;
 
+    // One sphere: the discriminant as a quadratic in the two 16-bit jitter draws (jx, jy) of the
+    // sample, the ray being (ux0 + sx*jx, uy0 + sy*jy, dz):
+    //   disc = jx*(pxx*jx + pxy*jy + px) + jy*(pyy*jy + py) + p0        5 fmas per sample
+    // pxx, pxy, pyy are the same for every pixel (SGPRs); px, py, p0 belong to the pixel.  Every
+    // term of the expansion is at most a few times M = h*h + dd*(oc.oc + r*r), so this evaluation
+    // is, like the direct one, within a few dozen unit roundoffs of M of the real value.
+    float pxx = 0.0f, pxy = 0.0f, pyy = 0.0f, px = 0.0f, py = 0.0f, p0 = 0.0f;
+    if constexpr(ONE) {
+        pxx = cc.q_uu * (sx * sx);
+        pxy = cc.q_uv * (sx * sy);
+        pyy = cc.q_vv * (sy * sy);
+        px = sx * __builtin_fmaf(2.0f * cc.q_uu, ux0, __builtin_fmaf(cc.q_uv, uy0, cc.q_u));
+        py = sy * __builtin_fmaf(2.0f * cc.q_vv, uy0, __builtin_fmaf(cc.q_uv, ux0, cc.q_v));
+        const float h0 = __builtin_fmaf(uy0, cc.oc[1], __builtin_fmaf(ux0, cc.oc[0], dz * cc.oc[2]));
+        const float dd0 = __builtin_fmaf(uy0, uy0, __builtin_fmaf(ux0, ux0, dz2));
+        p0 = __builtin_fmaf(-dd0, cc.c, h0 * h0);
+        if constexpr(EXACT) {
+            // screening: add the margin times an upper bound of M over the pixel's jitter range
+            // (all terms taken positive at the corner of the pixel farthest from the axes)
+            const float ua = fmaxf(fabsf(ux0), fabsf(__builtin_fmaf(65535.0f, sx, ux0)));
+            const float va = fmaxf(fabsf(uy0), fabsf(__builtin_fmaf(65535.0f, sy, uy0)));
+            const float hmax = __builtin_fmaf(ua, fabsf(cc.oc[0]), __builtin_fmaf(va, fabsf(cc.oc[1]), fabsf(dz * cc.oc[2])));
+            const float ddmax = __builtin_fmaf(ua, ua, __builtin_fmaf(va, va, dz2));
+            const float mmax = __builtin_fmaf(ddmax, cc.magnitude, hmax * hmax);
+            p0 = __builtin_fmaf(kScreenMargin * 1.001f, mmax, p0);
+        }
+    }
+
     f3 sum = {0.0f, 0.0f, 0.0f};
     uint32_t my_samples = 0;            // samples this wave traces per pixel (wave-uniform)
 
@@ -924,25 +956,34 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
                         // reference's six operations: it differs from the exact ray by a few ulps of the
                         // viewport extent, which moves the screening value by under 6e-6 of the
                         // magnitude -- inside the margin with room to spare.
+                        // One sphere, folded ray: the screening value is the pixel's quadratic in
+                        // the two jitter draws, margin included in its constant term.
                         f3 draw = {0.0f, 0.0f, dz};
-                        float rx, ry;
-                        if constexpr(FOLD) {
-                            rx = __builtin_fmaf(static_cast<float>(key >> 16), sx, ux0);
-                            ry = __builtin_fmaf(static_cast<float>(key & 0xffffu), sy, uy0);
-                        } else {
-                            draw = exact_draw(key);
-                            rx = draw.x;
-                            ry = draw.y;
-                        }
-                        const float dd = __builtin_fmaf(ry, ry, __builtin_fmaf(rx, rx, dz2));
                         bool maybe = false;
-                        for(uint32_t i = 0; i < n_spheres; i++) {
-                            const float4 k = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
-                            const float mag = ONE ? cc.magnitude : s_ctr[i].w;
-                            const float h = __builtin_fmaf(ry, k.y, __builtin_fmaf(rx, k.x, dz * k.z));
-                            const float q = h * h;
-                            const float screen = __builtin_fmaf(kScreenMargin, __builtin_fmaf(dd, mag, q), __builtin_fmaf(-dd, k.w, q));
-                            maybe = maybe || (screen >= 0.0f);
+                        if constexpr(ONE && FOLD) {
+                            const float jx = static_cast<float>(key >> 16), jy = static_cast<float>(key & 0xffffu);
+                            const float t1 = __builtin_fmaf(pxx, jx, __builtin_fmaf(pxy, jy, px));
+                            const float t2 = __builtin_fmaf(pyy, jy, py);
+                            maybe = __builtin_fmaf(jx, t1, __builtin_fmaf(jy, t2, p0)) >= 0.0f;
+                        } else {
+                            float rx, ry;
+                            if constexpr(FOLD) {
+                                rx = __builtin_fmaf(static_cast<float>(key >> 16), sx, ux0);
+                                ry = __builtin_fmaf(static_cast<float>(key & 0xffffu), sy, uy0);
+                            } else {
+                                draw = exact_draw(key);
+                                rx = draw.x;
+                                ry = draw.y;
+                            }
+                            const float dd = __builtin_fmaf(ry, ry, __builtin_fmaf(rx, rx, dz2));
+                            for(uint32_t i = 0; i < n_spheres; i++) {
+                                const float4 k = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
+                                const float mag = ONE ? cc.magnitude : s_ctr[i].w;
+                                const float h = __builtin_fmaf(ry, k.y, __builtin_fmaf(rx, k.x, dz * k.z));
+                                const float q = h * h;
+                                const float screen = __builtin_fmaf(kScreenMargin, __builtin_fmaf(dd, mag, q), __builtin_fmaf(-dd, k.w, q));
+                                maybe = maybe || (screen >= 0.0f);
+                            }
                         }
                         if constexpr(FOLD) {
                             if(maybe) draw = exact_draw(key);
@@ -1024,8 +1065,36 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
                 for(uint32_t sample = s0; sample < s1; sample++) {
                     const uint32_t key = pix_term + term;
                     term = sample_terms[sample + 1];        // next sample's term (table has one spare entry)
-                    const float dx = __builtin_fmaf(static_cast<float>(key >> 16), sx, ux0);
-                    const float dy = __builtin_fmaf(static_cast<float>(key & 0xffffu), sy, uy0);
+                    const float jx = static_cast<float>(key >> 16), jy = static_cast<float>(key & 0xffffu);
+                    if constexpr(ONE) {
+                        // most samples miss: decide that from the pixel's quadratic before anything else
+                        const float t1 = __builtin_fmaf(pxx, jx, __builtin_fmaf(pxy, jy, px));
+                        const float t2 = __builtin_fmaf(pyy, jy, py);
+                        const float disc = __builtin_fmaf(jx, t1, __builtin_fmaf(jy, t2, p0));
+                        if(disc >= 0.0f) {
+                            const float dx = __builtin_fmaf(jx, sx, ux0);
+                            const float dy = __builtin_fmaf(jy, sy, uy0);
+                            const float dd = __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, dz2));
+                            const float h = __builtin_fmaf(dy, cc.oc[1], __builtin_fmaf(dx, cc.oc[0], dz * cc.oc[2]));
+                            const float sq = __builtin_amdgcn_sqrtf(disc);
+                            const float inv = __builtin_amdgcn_rcpf(dd);
+                            const float tmin = kTMin * __builtin_amdgcn_rsqf(dd);       // t_min in units of |draw|
+                            float t = (h - sq) * inv;
+                            if(!(t > tmin)) t = (h + sq) * inv;
+                            if(t > tmin) {
+                                const f3 v = {__builtin_fmaf(dx, t, cam.x - cc.center[0]), __builtin_fmaf(dy, t, cam.y - cc.center[1]),
+                                              __builtin_fmaf(dz, t, cam.z - cc.center[2])};
+                                const float half_inv = 0.5f * __builtin_amdgcn_rsqf(dot3<false>(v, v));
+                                sum.x += __builtin_fmaf(v.x, half_inv, 0.5f);
+                                sum.y += __builtin_fmaf(v.y, half_inv, 0.5f);
+                                sum.z += __builtin_fmaf(v.z, half_inv, 0.5f);
+                                hits++;
+                            }
+                        }
+                        continue;
+                    }
+                    const float dx = __builtin_fmaf(jx, sx, ux0);
+                    const float dy = __builtin_fmaf(jy, sy, uy0);
                     const float dd = __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, dz2));
                     float closest = 3.402823466e+38f;
                     int hit = -1;
@@ -1444,6 +1513,14 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
             b->cc.c = occ - geom[0].w;
             b->cc.center[0] = geom[0].x; b->cc.center[1] = geom[0].y; b->cc.center[2] = geom[0].z;
             b->cc.magnitude = occ + geom[0].w;
+            const double kx = ocx, ky = ocy, c = b->cc.c;
+            const double dz = 0.0f - vc.cam[2], hz = dz * static_cast<double>(ocz);
+            b->cc.q_uu = static_cast<float>(kx * kx - c);
+            b->cc.q_uv = static_cast<float>(2.0 * kx * ky);
+            b->cc.q_vv = static_cast<float>(ky * ky - c);
+            b->cc.q_u = static_cast<float>(2.0 * kx * hz);
+            b->cc.q_v = static_cast<float>(2.0 * ky * hz);
+            b->cc.q_0 = static_cast<float>(hz * hz - c * dz * dz);
         }
         hipError_t e = hipMemcpyAsync(b->d_geom, geom, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
         if(e == hipSuccess) e = hipMemcpyAsync(b->d_matl, matl, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
