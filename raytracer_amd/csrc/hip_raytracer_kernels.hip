@@ -250,6 +250,10 @@ struct camera_consts {       // travels as a kernel argument (SGPRs)
     // h = (u, v, dz).oc and dd = u*u + v*v + dz*dz, written out as a quadratic in the ray's
     // viewport offsets: q_uu u*u + q_uv u*v + q_vv v*v + q_u u + q_v v + q_0
     float q_uu, q_uv, q_vv, q_u, q_v, q_0;
+    // fast build shading of a hit on sphere 0: colour = draw * (shade_scale * t) + shade_offset
+    float shade_scale;       // 0.5 / r
+    float shade_offset[3];   // 0.5 - 0.5 * oc / r
+    uint32_t near_root_only; // camera outside the sphere by more than t_min: a hit is the near root
 };
 
 // Relative margin of the exact build's conservative miss tests (see screen_sphere below).
@@ -1076,18 +1080,30 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
                             const float dy = __builtin_fmaf(jy, sy, uy0);
                             const float dd = __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, dz2));
                             const float h = __builtin_fmaf(dy, cc.oc[1], __builtin_fmaf(dx, cc.oc[0], dz * cc.oc[2]));
+                            // The hit is at draw * t, t = root / dd, root = h -+ sqrt(disc); it lies
+                            // beyond t_min when root > 0 and root*root > t_min^2 * dd.  With the
+                            // camera outside the sphere by more than t_min (near_root_only) the two
+                            // roots have the sign of h and the near one always passes.
+                            // A point of the sphere is a radius away from the centre, so the
+                            // normal is (draw*t - oc) / r without a normalisation, and its colour
+                            // 0.5*n + 0.5 = draw * (0.5 t / r) + (0.5 - 0.5 oc / r).  The sum over
+                            // the pixel's hits needs only sum(dx*s), sum(dy*s), sum(s) with
+                            // s = 0.5 t / r; the constant parts are added once, below.
                             const float sq = __builtin_amdgcn_sqrtf(disc);
-                            const float inv = __builtin_amdgcn_rcpf(dd);
-                            const float tmin = kTMin * __builtin_amdgcn_rsqf(dd);       // t_min in units of |draw|
-                            float t = (h - sq) * inv;
-                            if(!(t > tmin)) t = (h + sq) * inv;
-                            if(t > tmin) {
-                                const f3 v = {__builtin_fmaf(dx, t, cam.x - cc.center[0]), __builtin_fmaf(dy, t, cam.y - cc.center[1]),
-                                              __builtin_fmaf(dz, t, cam.z - cc.center[2])};
-                                const float half_inv = 0.5f * __builtin_amdgcn_rsqf(dot3<false>(v, v));
-                                sum.x += __builtin_fmaf(v.x, half_inv, 0.5f);
-                                sum.y += __builtin_fmaf(v.y, half_inv, 0.5f);
-                                sum.z += __builtin_fmaf(v.z, half_inv, 0.5f);
+                            float root = h - sq;
+                            bool ok;
+                            if(cc.near_root_only != 0u) {
+                                ok = h > 0.0f;
+                            } else {
+                                const float far_enough = (kTMin * kTMin) * dd;
+                                if(!(root > 0.0f && root * root > far_enough)) root = h + sq;
+                                ok = root > 0.0f && root * root > far_enough;
+                            }
+                            if(ok) {
+                                const float sc = (root * cc.shade_scale) * __builtin_amdgcn_rcpf(dd);
+                                sum.x = __builtin_fmaf(dx, sc, sum.x);
+                                sum.y = __builtin_fmaf(dy, sc, sum.y);
+                                sum.z += sc;
                                 hits++;
                             }
                         }
@@ -1146,6 +1162,13 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
                     hits += s_hits[wave + p][lane];
                 }
             }
+        }
+        if constexpr(ONE) {
+            // constant parts of the hits' colours (see the sample loop)
+            const float hf = static_cast<float>(hits);
+            sum.x = __builtin_fmaf(hf, cc.shade_offset[0], sum.x);
+            sum.y = __builtin_fmaf(hf, cc.shade_offset[1], sum.y);
+            sum.z = __builtin_fmaf(hf, cc.shade_offset[2], dz * sum.z);
         }
         const float misses = static_cast<float>(vc.spp - hits);
         sum.x = __builtin_fmaf(misses, bg.x, sum.x);
@@ -1262,7 +1285,8 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         }
         const uint32_t rows_per_group = static_cast<uint32_t>(kTileH) >> split_log2;
         const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + rows_per_group - 1) / rows_per_group);
-        const bool one = vc.n_spheres == 1;
+        // a sphere of (nearly) no radius has no usable 1/r: it goes through the list variant
+        const bool one = vc.n_spheres == 1 && std::isfinite(b->cc.shade_scale) && b->cc.shade_scale < 1e18f;
         const bool fold = (vc.flags & kFlagFoldScreen) != 0;
 #define AEHIP_LAUNCH_CAMERA(E, O, F)                                                                                   \
     do {                                                                                                               \
@@ -1521,6 +1545,12 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
             b->cc.q_u = static_cast<float>(2.0 * kx * hz);
             b->cc.q_v = static_cast<float>(2.0 * ky * hz);
             b->cc.q_0 = static_cast<float>(hz * hz - c * dz * dz);
+            const double r0 = std::sqrt(static_cast<double>(geom[0].w));
+            b->cc.shade_scale = static_cast<float>(0.5 / r0);               // inf for a point sphere: see launch()
+            b->cc.shade_offset[0] = static_cast<float>(0.5 - 0.5 * kx / r0);
+            b->cc.shade_offset[1] = static_cast<float>(0.5 - 0.5 * ky / r0);
+            b->cc.shade_offset[2] = static_cast<float>(0.5 - 0.5 * static_cast<double>(ocz) / r0);
+            b->cc.near_root_only = std::sqrt(static_cast<double>(occ)) - r0 > 1.001 * static_cast<double>(kTMin) ? 1u : 0u;
         }
         hipError_t e = hipMemcpyAsync(b->d_geom, geom, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
         if(e == hipSuccess) e = hipMemcpyAsync(b->d_matl, matl, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
