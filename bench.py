@@ -41,6 +41,11 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3     # MI355X datasheet FP32 vector peak (256 CU 
 FP32_FMA_MEASURED_TFLOPS = 108.0    # what back-to-back v_fma_f32 sustains on this part (tools/valu_peak.hip)
 FP32_UNFUSED_MEASURED_TFLOPS = 54.0 # v_mul_f32 / v_add_f32 issue rate: the ceiling of code that may not fuse (exact build)
 HBM_PEAK_GBS = 8000.0
+VALU_ISSUE_MEASURED = 54.0e12       # lane-instructions/s that back-to-back v_fma_f32 / v_mul_f32 sustain (tools/valu_peak.hip)
+# VALU wave-instructions one launch of the default workload (4K, 1024 spp, one GPU) executes:
+# SQ_INSTS_VALU per launch in the committed rocprofv3 --pmc summaries
+EXECUTED_VALU_WAVE_INSTRUCTIONS = {"fast": (1652748812, "profiles/r01_d_bench_fast.txt"),
+                                   "exact": (5406209044, "profiles/r01_d_bench_exact.txt")}
 
 # Algorithmic FP32 flops of the default-scene path pass, counted on the reference's formulas with
 # div and sqrt = 1 flop each and integer / compare / convert = 0:
@@ -256,8 +261,21 @@ def main():
                 "algorithmic_vs_measured_fma_rate": achieved / FP32_FMA_MEASURED_TFLOPS,
                 "vgprs": st.vgprs,
                 "lds_bytes": st.lds_bytes,
+                "note": "achieved counts the flops of the reference's formulas per sample (36 miss / 67 hit); the "
+                        "kernels reach the same results with fewer operations (misses decided by a 5-fma quadratic "
+                        "per sample, no normalisation in the fast build), so frac can exceed 1; 'executed' prices "
+                        "the instructions really issued against the measured VALU issue rate",
             },
         }
+        if args.spp == 1024 and args.depth == 8:
+            count, source = EXECUTED_VALU_WAVE_INSTRUCTIONS[args.mode]
+            lane_ops = count * 64.0 / world / kernel_s
+            line["roofline"]["executed"] = {
+                "valu_wave_instructions_per_launch": count / world, "source": source,
+                "valu_instructions_per_sample": count * 64.0 / paths_total,
+                "valu_lane_ops_per_s": lane_ops, "measured_issue_ceiling": VALU_ISSUE_MEASURED,
+                "frac_of_issue_ceiling": lane_ops / VALU_ISSUE_MEASURED,
+            }
         if second is not None:
             e2, k2, st2 = second
             steps2 = max(2, args.steps // 2)
