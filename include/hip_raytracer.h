@@ -144,7 +144,8 @@ int aehip_backend_trace(aehip_backend *backend);
 /* Same render, outputs left in device memory (for callers that keep the image on the GPU or
  * gather bands across GPUs): argb_dev = width*row_count u32; rgba_dev (nullable) =
  * width*row_count float4 holding the averaged colour before quantisation.  Asynchronous on
- * `hip_stream` (a hipStream_t; NULL = the backend's own stream, which the call then waits on). */
+ * `hip_stream` (a hipStream_t; NULL = the backend's own stream, which is ordered after work already
+ * queued on the device's null stream and which the call then waits on). */
 int aehip_backend_trace_device(aehip_backend *backend, uint32_t *argb_dev, float *rgba_dev, void *hip_stream);
 
 int aehip_backend_stats(aehip_backend *backend, aehip_stats *out);

@@ -1391,7 +1391,9 @@ int aehip_backend_create(int device, uint32_t *framebuffer, aehip_backend **out)
     b->framebuffer = framebuffer;
 
     hipError_t e = hipSetDevice(device);
-    if(e == hipSuccess) e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    // a blocking stream: ordered after whatever the caller queued on the device's null stream
+    // (a buffer it just cleared, say) before handing us that buffer
+    if(e == hipSuccess) e = hipStreamCreateWithFlags(&b->stream, hipStreamDefault);
     if(e == hipSuccess) e = hipEventCreate(&b->ev_begin);
     if(e == hipSuccess) e = hipEventCreate(&b->ev_end);
     if(e == hipSuccess) e = hipEventCreate(&b->ev_copy);
