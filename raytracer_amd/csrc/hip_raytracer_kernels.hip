@@ -683,9 +683,11 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
 
     if(valid) {
         const float n = static_cast<float>(vc.spp);
-        const float r = clamp01(rt_div<EXACT>(sum.x, n));
-        const float g = clamp01(rt_div<EXACT>(sum.y, n));
-        const float b = clamp01(rt_div<EXACT>(sum.z, n));
+        // the mean is a true division in both builds (once per pixel): an approximate reciprocal
+        // would turn a row of exact 1.0 samples into 0.99999994 and the truncating pack into 254
+        const float r = clamp01(sum.x / n);
+        const float g = clamp01(sum.y / n);
+        const float b = clamp01(sum.z / n);
         const size_t idx = static_cast<size_t>(row) * vc.width + x;
         argb[idx] = pack_argb32(r, g, b);
         if(rgba) rgba[idx] = make_float4(r, g, b, 1.0f);
@@ -805,10 +807,10 @@ __global__ __launch_bounds__(kBlock) void path_pool_kernel(view_consts vc, const
         const uint32_t x = x_base + (lane & 15u);
         const uint32_t row = row_base + (lane >> 4);
         if(x < vc.width && row < vc.row_count) {
-            const float inv = __builtin_amdgcn_rcpf(static_cast<float>(vc.spp));
-            const float r = clamp01(s_acc[wave][0][lane] * inv);
-            const float g = clamp01(s_acc[wave][1][lane] * inv);
-            const float b = clamp01(s_acc[wave][2][lane] * inv);
+            const float n = static_cast<float>(vc.spp);     // true division, as in the other passes
+            const float r = clamp01(s_acc[wave][0][lane] / n);
+            const float g = clamp01(s_acc[wave][1][lane] / n);
+            const float b = clamp01(s_acc[wave][2][lane] / n);
             const size_t idx = static_cast<size_t>(row) * vc.width + x;
             argb[idx] = pack_argb32(r, g, b);
             if(rgba) rgba[idx] = make_float4(r, g, b, 1.0f);
@@ -1178,9 +1180,11 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
 
     if(valid && part == 0u) {
         const float n = static_cast<float>(vc.spp);
-        const float r = clamp01(rt_div<EXACT>(sum.x, n));
-        const float g = clamp01(rt_div<EXACT>(sum.y, n));
-        const float b = clamp01(rt_div<EXACT>(sum.z, n));
+        // the mean is a true division in both builds (once per pixel): an approximate reciprocal
+        // would turn a row of exact 1.0 samples into 0.99999994 and the truncating pack into 254
+        const float r = clamp01(sum.x / n);
+        const float g = clamp01(sum.y / n);
+        const float b = clamp01(sum.z / n);
         const size_t idx = static_cast<size_t>(row) * vc.width + x;
         argb[idx] = pack_argb32(r, g, b);
         if(rgba) rgba[idx] = make_float4(r, g, b, 1.0f);
