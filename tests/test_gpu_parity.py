@@ -289,20 +289,25 @@ def test_regeneration_keeps_lanes_busy_and_never_changes_the_image():
     assert util_on >= 1.25 * util_off
 
 
-def test_pooled_fast_pass_traces_the_same_paths_as_the_per_lane_pass():
-    """The fast build deals (pixel, sample) items to lanes by ballot; the paths are keyed by
-    (pixel, sample) so they are the same paths as the one-lane-per-pixel pass (selected here with
-    no_regen), summed in another order: equal ray counts, colours equal to float rounding."""
+@pytest.mark.parametrize("size,spp", [((200, 120), 8), ((1920, 1080), 8)])
+def test_streamed_fast_pass_traces_the_same_paths_as_the_per_lane_pass(size, spp):
+    """The fast build deals (pixel, sample) items to lanes by ballot, and its persistent waves take
+    strip after strip from a queue (the 1080p case has four times more strips than the chip holds
+    waves); the paths are keyed by (pixel, sample) so they are the same paths as the
+    one-lane-per-pixel pass (selected here with no_regen), summed in another order: equal ray
+    counts, colours equal to float rounding."""
     sph = scenes.divergence_scene()
-    w, h = 200, 120          # not a multiple of the 16x16 tile: exercises out-of-image items
-    flags = dict(spp=8, max_depth=50, seed=7, jitter=True, spheres=sph, count_rays=True, fast=True)
-    _, pooled, st_pool = render_device(w, h, **flags)
+    w, h = size              # 200x120 is not a multiple of the 16x4 strip: exercises out-of-image items
+    flags = dict(spp=spp, max_depth=50, seed=7, jitter=True, spheres=sph, count_rays=True, fast=True)
+    _, streamed, st_stream = render_device(w, h, **flags)
+    _, again, _ = render_device(w, h, **flags)
+    np.testing.assert_array_equal(streamed, again)          # which wave takes which strip changes nothing
     back = rt.HipRaytracer(None)
     import torch
 
     try:
         f = rt.FLAG_JITTER | rt.FLAG_FAST | rt.FLAG_COUNT_RAYS | rt.FLAG_NO_REGEN
-        assert back.setup(w, h, 8, 50, 7, f, rt.PASS_PATH, spheres=sph)
+        assert back.setup(w, h, spp, 50, 7, f, rt.PASS_PATH, spheres=sph)
         argb = torch.zeros((h, w), dtype=torch.int32, device="cuda")
         rgba = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
         back.trace_device(argb.data_ptr(), rgba.data_ptr(), torch.cuda.current_stream().cuda_stream)
@@ -311,9 +316,11 @@ def test_pooled_fast_pass_traces_the_same_paths_as_the_per_lane_pass():
         per_lane = rgba.cpu().numpy()
     finally:
         back.close()
-    assert st_pool.rays == st_lane.rays
-    assert float(np.max(np.abs(pooled - per_lane))) <= 2e-6
-    assert st_pool.rays / st_pool.lane_slots > st_lane.rays / st_lane.lane_slots
+    assert st_stream.rays == st_lane.rays
+    assert float(np.max(np.abs(streamed - per_lane))) <= 2e-6
+    assert st_stream.rays / st_stream.lane_slots > st_lane.rays / st_lane.lane_slots
+    if w * h > 1_000_000:
+        assert st_stream.rays / st_stream.lane_slots >= 0.8        # 0.84 measured at 8 spp, 0.93 at 16, 0.99 at 64
 
 
 # ------------------------------------------------------------------ one frame on several devices
@@ -400,12 +407,12 @@ def test_tiled_bands_equal_the_whole_image(world, tile_rows, size):
     for fast in (False, True):
         whole_d, _ = rt.render(w, h, spp=8, max_depth=8, seed=3, jitter=True, fast=fast)
         np.testing.assert_array_equal(render_tiled(w, h, world, tile_rows, spp=8, max_depth=8, seed=3, jitter=True, fast=fast), whole_d)
-    # fast build, pooled pass (>= 16 spheres): the order in which a pixel's samples are added may
-    # differ between launches of different shape, so one code of slack
+    # fast build, streamed pass (>= 16 spheres): fixed-point pixel sums, independent of the order
+    # in which paths finish and so of the launch's shape
     many = scenes.divergence_scene()
     whole_f, _ = rt.render(w, h, spp=4, max_depth=6, seed=9, jitter=True, fast=True, spheres=many)
     tiled_f = render_tiled(w, h, world, tile_rows, spp=4, max_depth=6, seed=9, jitter=True, fast=True, spheres=many)
-    assert np.abs(channels(tiled_f) - channels(whole_f)).max() <= 1
+    np.testing.assert_array_equal(tiled_f, whole_f)
 
 
 def test_setup_rejects_bad_tile_requests():

@@ -13,9 +13,18 @@ ap.add_argument("--bands", type=int, default=8)
 ap.add_argument("--mode", default="fast")
 ap.add_argument("--spp", type=int, default=1024)
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--scene", default="default", help="default | showcase | divergence | stress:<count>")
+ap.add_argument("--depth", type=int, default=8)
 ap.add_argument("--tile-rows", type=int, default=0, help="0 = contiguous bands, T = tiles of T rows dealt round-robin")
 a = ap.parse_args()
 W, H = 3840, 2160
+from raytracer_amd import scenes
+if a.scene == "default":
+    spheres = None
+elif a.scene.startswith("stress:"):
+    spheres = scenes.stress_scene(int(a.scene.split(":")[1]), 42)
+else:
+    spheres = scenes.SCENES[a.scene]()
 flags = rt.FLAG_JITTER | (rt.FLAG_FAST if a.mode == "fast" else 0)
 buf = torch.zeros((H, W), dtype=torch.int32, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
@@ -23,7 +32,7 @@ times = []
 for r in range(a.bands):
     back = rt.HipRaytracer(None)
     band = tiled_band(H, a.bands, r, a.tile_rows)
-    assert back.setup(W, H, spp=a.spp, max_depth=8, seed=1, flags=flags, pass_=rt.PASS_PATH, **band)
+    assert back.setup(W, H, spp=a.spp, max_depth=a.depth, seed=1, flags=flags, pass_=rt.PASS_PATH, spheres=spheres, **band)
     # launches back to back, as a render loop issues them (an idle GPU between launches clocks down)
     for _ in range(3):
         back.trace_device(buf.data_ptr(), None, stream)
