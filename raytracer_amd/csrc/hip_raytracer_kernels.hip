@@ -421,13 +421,10 @@ __device__ __forceinline__ void resolve_sphere(const float4 g, int index, float 
         t_near = h - sq;
         t_far = h + sq;
     }
-    float t = t_near;
-    bool ok = (t > kTMin) && (t < closest);
-    if(!ok) {
-        t = t_far;
-        ok = (t > kTMin) && (t < closest);
-    }
-    if(ok) {
+    // near root if it lies in (t_min, closest), else the far root if it does.  A near root at or
+    // beyond `closest` leaves nothing for the far one (t_far >= t_near), so one range test serves.
+    const float t = t_near > kTMin ? t_near : t_far;
+    if((t > kTMin) && (t < closest)) {
         closest = t;
         hit = index;
     }
