@@ -377,7 +377,7 @@ __device__ __forceinline__ void start_path(const view_consts &vc, uint32_t pix_t
 // Screening value, >= 0 means "may be hit":
 //   fast build:  the discriminant itself in half-b form with a = d.d taken as 1 (d is
 //                normalised): h*h - c, h = d.oc, c = oc.oc - r*r, all fused.
-//   exact build: the same fused value plus a margin, h*h - c + 3e-5*(h*h + oc.oc + r*r).  A
+//   exact build: the same fused value plus a margin of 3e-5 times at least h*h + oc.oc + r*r.  A
 //                quarter of the exact discriminant b*b - 4ac (src/shapes.cpp:15-20) and this
 //                fused h*h - c are two roundings of the same real number; each is off by at
 //                most about a dozen unit roundoffs (6e-8) of the magnitudes that enter it,
@@ -392,12 +392,14 @@ __device__ __forceinline__ float screen_sphere(const float4 g, const f3 o, const
     const float h = __builtin_fmaf(d.z, oc.z, __builtin_fmaf(d.y, oc.y, d.x * oc.x));
     const float c = __builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, __builtin_fmaf(oc.x, oc.x, -g.w)));
     h_out = h;
-    const float disc = __builtin_fmaf(h, h, -c);
     if constexpr(EXACT) {
-        const float magnitude = __builtin_fmaf(h, h, __builtin_fmaf(g.w, 2.0f, c));     // h*h + oc.oc + r*r
-        return __builtin_fmaf(kScreenMargin, magnitude, disc);
+        // h*h - c + margin * (2 oc.oc + r*r), the last factor being at least the magnitude
+        // h*h + oc.oc + r*r (the direction has unit length to rounding, so h*h <= oc.oc), written
+        // with oc.oc = c + r*r:  h*h - (1 - 2 margin) c + 3 margin r*r
+        const float u = __builtin_fmaf(c, -(1.0f - 2.0f * kScreenMargin), g.w * (3.0f * kScreenMargin));
+        return __builtin_fmaf(h, h, u);
     } else {
-        return disc;
+        return __builtin_fmaf(h, h, -c);
     }
 }
 
