@@ -112,6 +112,18 @@ def cpu_baseline(target_seconds: float):
     return out
 
 
+def device_facts(torch, index):
+    """What the peak figures assume: 256 CUs at 2.4 GHz."""
+    p = torch.cuda.get_device_properties(index)
+    facts = {"name": p.name, "arch": getattr(p, "gcnArchName", ""), "compute_units": p.multi_processor_count,
+             "hbm_gib": round(p.total_memory / 2 ** 30, 1)}
+    try:
+        facts["clock_mhz"] = torch.cuda.clock_rate(index)       # current shader clock, from the SMI library
+    except Exception:
+        pass
+    return facts
+
+
 def frame_flops(paths, pixels):
     return paths * (HIT_FRACTION_16_9 * FLOP_SAMPLE_HIT + (1 - HIT_FRACTION_16_9) * FLOP_SAMPLE_MISS) + pixels * FLOP_PIXEL
 
@@ -236,11 +248,12 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"default scene {WIDTH}x{HEIGHT}, {args.spp} spp jittered, max depth {args.depth}, "
-                            f"4-row tiles dealt round-robin to {world} GPU(s), gather to rank 0",
+                            + (f"4-row tiles dealt round-robin to {world} GPUs, gather to rank 0" if world > 1 else "one GPU"),
                 "arithmetic": args.mode,
                 "rays_per_path": 1,
             },
             "kernel_ms": kernel_s * 1e3,
+            "device": device_facts(torch, dev_index),
             "gathered_frame_equals_single_gpu_frame": verified,
             "rays_per_s": paths_total / (elapsed / args.steps),
             "roofline": {
