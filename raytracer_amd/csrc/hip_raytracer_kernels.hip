@@ -905,7 +905,7 @@ __global__ __launch_bounds__(kBlock) void path_stream_kernel(view_consts vc, con
 // per wave and adds them once at the end.
 // ------------------------------------------------------------------------------------------
 
-template <bool EXACT, bool ONE, bool FOLD>
+template <bool EXACT, bool ONE, bool FOLD, bool AXIAL>
 __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_consts cc, uint32_t split_log2,
                                                         const float4 *__restrict__ geom,
                                                         const uint32_t *__restrict__ sample_terms,
@@ -959,6 +959,7 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
     // One sphere: the discriminant as a quadratic in the two 16-bit jitter draws (jx, jy) of the
     // sample, the ray being (ux0 + sx*jx, uy0 + sy*jy, dz):
     //   disc = jx*(pxx*jx + pxy*jy + px) + jy*(pyy*jy + py) + p0        5 fmas per sample
+    // (4 when the sphere's centre is on the camera axis, AXIAL: pxy is then 0).
     // pxx, pxy, pyy are the same for every pixel (SGPRs); px, py, p0 belong to the pixel.  Every
     // term of the expansion is at most a few times M = h*h + dd*(oc.oc + r*r), so this evaluation
     // is, like the direct one, within a few dozen unit roundoffs of M of the real value.
@@ -1027,7 +1028,7 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
                         bool maybe = false;
                         if constexpr(ONE && FOLD) {
                             const float jx = static_cast<float>(key >> 16), jy = static_cast<float>(key & 0xffffu);
-                            const float t1 = __builtin_fmaf(pxx, jx, __builtin_fmaf(pxy, jy, px));
+                            const float t1 = AXIAL ? __builtin_fmaf(pxx, jx, px) : __builtin_fmaf(pxx, jx, __builtin_fmaf(pxy, jy, px));
                             const float t2 = __builtin_fmaf(pyy, jy, py);
                             maybe = __builtin_fmaf(jx, t1, __builtin_fmaf(jy, t2, p0)) >= 0.0f;
                         } else {
@@ -1127,13 +1128,16 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
             my_samples += s1 - s0;
             uint32_t term = sample_terms[s0];
             if(valid) {
+                // unrolled: with 8 vector instructions per missing sample the loop's own scalar
+                // instructions (counter, address, compare, branch) are what limits issue
+#pragma unroll 4
                 for(uint32_t sample = s0; sample < s1; sample++) {
                     const uint32_t key = pix_term + term;
                     term = sample_terms[sample + 1];        // next sample's term (table has one spare entry)
                     const float jx = static_cast<float>(key >> 16), jy = static_cast<float>(key & 0xffffu);
                     if constexpr(ONE) {
                         // most samples miss: decide that from the pixel's quadratic before anything else
-                        const float t1 = __builtin_fmaf(pxx, jx, __builtin_fmaf(pxy, jy, px));
+                        const float t1 = AXIAL ? __builtin_fmaf(pxx, jx, px) : __builtin_fmaf(pxx, jx, __builtin_fmaf(pxy, jy, px));
                         const float t2 = __builtin_fmaf(pyy, jy, py);
                         const float disc = __builtin_fmaf(jx, t1, __builtin_fmaf(jy, t2, p0));
                         if(disc >= 0.0f) {
@@ -1352,20 +1356,24 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         // a sphere of (nearly) no radius has no usable 1/r: it goes through the list variant
         const bool one = vc.n_spheres == 1 && std::isfinite(b->cc.shade_scale) && b->cc.shade_scale < 1e18f;
         const bool fold = (vc.flags & kFlagFoldScreen) != 0;
-#define AEHIP_LAUNCH_CAMERA(E, O, F)                                                                                   \
+#define AEHIP_LAUNCH_CAMERA(E, O, F, A)                                                                                \
     do {                                                                                                               \
-        func = reinterpret_cast<const void *>(camera_kernel<E, O, F>);                                                 \
-        hipLaunchKernelGGL((camera_kernel<E, O, F>), grid, dim3(kBlock), 0, stream, vc, b->cc, split_log2, b->d_geom,  \
-                           b->d_sample_terms, argb_dev, rgba, b->d_rays);                                              \
+        func = reinterpret_cast<const void *>(camera_kernel<E, O, F, A>);                                              \
+        hipLaunchKernelGGL((camera_kernel<E, O, F, A>), grid, dim3(kBlock), 0, stream, vc, b->cc, split_log2,          \
+                           b->d_geom, b->d_sample_terms, argb_dev, rgba, b->d_rays);                                   \
     } while(0)
+        // the quadratic's cross term vanishes when the sphere's centre is on the camera axis
+        const bool axial = one && b->cc.q_uv == 0.0f;
         if(exact) {
-            if(one && fold) AEHIP_LAUNCH_CAMERA(true, true, true);
-            else if(one) AEHIP_LAUNCH_CAMERA(true, true, false);
-            else if(fold) AEHIP_LAUNCH_CAMERA(true, false, true);
-            else AEHIP_LAUNCH_CAMERA(true, false, false);
+            if(one && fold && axial) AEHIP_LAUNCH_CAMERA(true, true, true, true);
+            else if(one && fold) AEHIP_LAUNCH_CAMERA(true, true, true, false);
+            else if(one) AEHIP_LAUNCH_CAMERA(true, true, false, false);
+            else if(fold) AEHIP_LAUNCH_CAMERA(true, false, true, false);
+            else AEHIP_LAUNCH_CAMERA(true, false, false, false);
         } else {
-            if(one) AEHIP_LAUNCH_CAMERA(false, true, false);
-            else AEHIP_LAUNCH_CAMERA(false, false, false);
+            if(one && axial) AEHIP_LAUNCH_CAMERA(false, true, false, true);
+            else if(one) AEHIP_LAUNCH_CAMERA(false, true, false, false);
+            else AEHIP_LAUNCH_CAMERA(false, false, false, false);
         }
 #undef AEHIP_LAUNCH_CAMERA
     } else {
