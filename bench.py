@@ -44,8 +44,8 @@ HBM_PEAK_GBS = 8000.0
 VALU_ISSUE_MEASURED = 54.0e12       # lane-instructions/s that back-to-back v_fma_f32 / v_mul_f32 sustain (tools/valu_peak.hip)
 # VALU wave-instructions one launch of the default workload (4K, 1024 spp, one GPU) executes:
 # SQ_INSTS_VALU per launch in the committed rocprofv3 --pmc summaries
-EXECUTED_VALU_WAVE_INSTRUCTIONS = {"fast": (1652748812, "profiles/r01_d_bench_fast.txt"),
-                                   "exact": (5406209044, "profiles/r01_d_bench_exact.txt")}
+EXECUTED_VALU_WAVE_INSTRUCTIONS = {"fast": (1521852812, "profiles/r01_e_bench_fast.txt"),
+                                   "exact": (5272461844, "profiles/r01_e_bench_exact.txt")}
 
 # Algorithmic FP32 flops of the default-scene path pass, counted on the reference's formulas with
 # div and sqrt = 1 flop each and integer / compare / convert = 0:
@@ -61,8 +61,8 @@ HIT_FRACTION_16_9 = 1832112.0 / 8294400.0   # sphere pixels in the reference's o
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)        # a frame is ~2 ms: the first dozen run below the
+    ap.add_argument("--warmup", type=int, default=10)       # clocks the GPU settles at, so warm up that long
     ap.add_argument("--mode", choices=["fast", "exact"], default="fast")
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--depth", type=int, default=8)
