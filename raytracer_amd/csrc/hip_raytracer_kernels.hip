@@ -888,6 +888,173 @@ __global__ __launch_bounds__(kBlock) void path_stream_kernel(view_consts vc, con
 }
 
 // ------------------------------------------------------------------------------------------
+// streamed path pass, exact build.
+//
+// The exact build must add a pixel's samples in the specified order, so finished paths cannot be
+// accumulated as they come.  Instead each path's radiance is stored under its (pixel, sample) in
+// a device buffer, one block of up to AEHIP_SAMPLE_BLOCK samples per launch, and a second kernel
+// adds the block's samples in sample order and the block sums in block order.  The tracing
+// kernel then has no per-strip state at all beyond the dealing cursor: persistent waves take
+// strip after strip from the queue and deal each strip's items to whichever lanes are free, as in
+// the fast build, and any number of strips can be in flight in one wave.  The buffer costs 12
+// bytes per path of HBM traffic each way -- nothing beside the tracing -- and 768 bytes per pixel
+// of memory for blocks of 64.
+// ------------------------------------------------------------------------------------------
+
+struct radiance3 {
+    float r, g, b;
+};
+
+__global__ __launch_bounds__(kBlock) void path_stream_exact_kernel(view_consts vc, const float4 *__restrict__ geom,
+                                                                   const float4 *__restrict__ matl,
+                                                                   const uint32_t *__restrict__ kind,
+                                                                   const uint32_t *__restrict__ sample_terms,
+                                                                   radiance3 *__restrict__ radiance, uint32_t sample_begin,
+                                                                   uint32_t sample_count, unsigned long long *ray_counter,
+                                                                   uint32_t *strip_queue) {
+    constexpr int kWaves = kBlock / 64;
+    __shared__ uint32_t s_term[kWaves][64];          // per-pixel key terms of the strip being dealt
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+    const uint32_t strips_x = (vc.width + kTileW - 1) / kTileW;
+    const uint32_t strips_y = (vc.row_count + 3u) / 4u;
+    const uint32_t n_strips = strips_x * strips_y;
+    const uint32_t pool = 64u * sample_count;        // items of one strip in this launch
+
+    // wave-uniform state
+    uint32_t cursor = pool;                          // next undealt item of the current strip (pool = none left)
+    bool queue_empty = false;
+    uint32_t strip = 0, strip_x0 = 0, strip_row0 = 0;
+
+    // lane state
+    uint32_t nrays = 0, iterations = 0;
+    uint32_t y = 0;
+    size_t slot = 0;                                 // where this lane's path stores its radiance
+    bool tracing = false;
+    path_state ps;
+    ps.o = ps.d = ps.thr = f3{0.0f, 0.0f, 0.0f};
+    ps.rng = 0;
+    ps.bounce = 0;
+
+    for(;;) {
+        const unsigned long long want = __ballot(!tracing);
+        if(want != 0ull) {
+            if(cursor >= pool && !queue_empty) {
+                uint32_t id = 0;
+                if(lane == 0) id = atomicAdd(strip_queue, 1u);
+                id = __builtin_amdgcn_readfirstlane(id);
+                if(id >= n_strips) {
+                    queue_empty = true;
+                } else {
+                    strip = id;
+                    const uint32_t sy = id / strips_x;
+                    strip_x0 = (id - sy * strips_x) * kTileW;
+                    strip_row0 = sy * 4u;
+                    cursor = 0;
+                    __builtin_amdgcn_wave_barrier();
+                    s_term[wave][lane] = pixel_term(vc.seed_hash, image_row(vc, strip_row0 + (lane >> 4)) * vc.width + strip_x0 + (lane & 15u));
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if(cursor < pool) {
+                const uint32_t before = __builtin_popcountll(want & ((1ull << lane) - 1ull));
+                const uint32_t item = cursor + before;
+                cursor += min(static_cast<uint32_t>(__builtin_popcountll(want)), pool - cursor);
+                if(!tracing && item < pool) {
+                    const uint32_t pix = item & 63u;
+                    const uint32_t local = item >> 6;
+                    const uint32_t x = strip_x0 + (pix & 15u);
+                    const uint32_t row = strip_row0 + (pix >> 4);
+                    if(x < vc.width && row < vc.row_count) {
+                        y = image_row(vc, row);
+                        slot = (static_cast<size_t>(strip) * AEHIP_SAMPLE_BLOCK + local) * 64u + pix;
+                        start_path<true>(vc, s_term[wave][pix], sample_terms, x, y, sample_begin + local, ps);
+                        tracing = true;
+                    }
+                    // an item of a pixel outside the image is simply dropped
+                }
+            }
+        }
+
+        if(!__any(tracing)) {
+            if(queue_empty && cursor >= pool) break;
+            continue;               // only out-of-image items were dealt, or the next strip is due
+        }
+        iterations++;
+        if(tracing) {
+            const float a = dot3<true>(ps.d, ps.d);
+            float closest = 3.402823466e+38f;
+            int hit = -1;
+            intersect_chunk<true>(geom, vc.n_spheres, 0, ps.o, ps.d, 2.0f * a, 4.0f * a, closest, hit);
+            nrays++;
+            f3 L;
+            if(shade_segment<true>(vc, y, hit, closest, geom, matl, kind, ps, L)) {
+                radiance[slot] = radiance3{L.x, L.y, L.z};
+                tracing = false;
+            }
+        }
+    }
+
+    if(vc.flags & AEHIP_FLAG_COUNT_RAYS) {
+        uint32_t v = nrays;
+#pragma unroll
+        for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if(lane == 0) {
+            atomicAdd(ray_counter, static_cast<unsigned long long>(v));
+            atomicAdd(ray_counter + 1, 64ull * iterations);
+        }
+    }
+}
+
+// Adds one block's samples in sample order, then the block sum to the pixel's total; the last
+// block's launch takes the mean and packs.  One wave per strip, lane l owns pixel l: the 64
+// lanes read 768 contiguous bytes per sample.
+__global__ __launch_bounds__(kBlock) void resolve_block_kernel(view_consts vc, const radiance3 *__restrict__ radiance,
+                                                               radiance3 *__restrict__ totals, uint32_t sample_count,
+                                                               uint32_t first_block, uint32_t last_block,
+                                                               uint32_t *__restrict__ argb, float4 *__restrict__ rgba) {
+    const uint32_t strips_x = (vc.width + kTileW - 1) / kTileW;
+    const uint32_t strips_y = (vc.row_count + 3u) / 4u;
+    const uint32_t strip = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    if(strip >= strips_x * strips_y) return;
+    const uint32_t sy = strip / strips_x;
+    const uint32_t x = (strip - sy * strips_x) * kTileW + (lane & 15u);
+    const uint32_t row = sy * 4u + (lane >> 4);
+    if(x >= vc.width || row >= vc.row_count) return;
+
+    const radiance3 *p = radiance + static_cast<size_t>(strip) * AEHIP_SAMPLE_BLOCK * 64u + lane;
+    f3 block = {0.0f, 0.0f, 0.0f};
+    for(uint32_t s = 0; s < sample_count; s++) {
+        const radiance3 v = p[static_cast<size_t>(s) * 64u];
+        block.x += v.r;
+        block.y += v.g;
+        block.z += v.b;
+    }
+    const size_t idx = static_cast<size_t>(row) * vc.width + x;
+    f3 sum = {0.0f, 0.0f, 0.0f};
+    if(!first_block) {
+        const radiance3 t = totals[idx];
+        sum = f3{t.r, t.g, t.b};
+    }
+    sum.x += block.x;
+    sum.y += block.y;
+    sum.z += block.z;
+    if(last_block) {
+        const float n = static_cast<float>(vc.spp);
+        const float r = clamp01(sum.x / n);
+        const float g = clamp01(sum.y / n);
+        const float b = clamp01(sum.z / n);
+        argb[idx] = pack_argb32(r, g, b);
+        if(rgba) rgba[idx] = make_float4(r, g, b, 1.0f);
+    } else {
+        totals[idx] = radiance3{sum.x, sum.y, sum.z};
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // camera pass: the path pass specialised for scenes in which every surface ends the path
 // (all materials NORMAL -- the reference's scene).  Every path is one segment from the camera,
 // so the sample loop is wave-uniform, the per-sphere terms that only depend on the ray origin
@@ -1314,6 +1481,9 @@ struct aehip_backend {
     unsigned long long *d_rays = nullptr;    // ray segments, lane slots, strip queue of the streamed pass
     uint32_t *d_sample_terms = nullptr;      // spp + 1 words: per-sample key terms (+1 spare for prefetch)
     uint32_t sample_terms_capacity = 0;
+    radiance3 *d_radiance = nullptr;         // exact streamed pass: one block of per-path radiance
+    radiance3 *d_totals = nullptr;           //   and the per-pixel sums of finished blocks
+    size_t radiance_capacity = 0, totals_capacity = 0;   // in elements
 
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_copy = nullptr;
@@ -1404,6 +1574,25 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
             func = reinterpret_cast<const void *>(path_stream_kernel);
             hipLaunchKernelGGL(path_stream_kernel, dim3(groups), dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind,
                                b->d_sample_terms, argb_dev, rgba, b->d_rays, reinterpret_cast<uint32_t *>(b->d_rays + 2));
+        } else if(exact && list == kListScalar && !(vc.flags & AEHIP_FLAG_NO_REGEN) && vc.n_spheres >= kPoolMinSpheres && vc.max_depth > 1 &&
+                  b->d_radiance != nullptr) {
+            // exact build, streamed: one launch pair per block of samples
+            int per_cu = 0;
+            AEHIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_stream_exact_kernel, kBlock, 0));
+            const uint32_t strips = ((vc.width + kTileW - 1) / kTileW) * ((vc.row_count + 3u) / 4u);
+            const uint32_t resident = static_cast<uint32_t>(per_cu > 0 ? per_cu : 1) * static_cast<uint32_t>(b->cu_count);
+            const uint32_t groups = std::min(resident, (strips + 3u) / 4u);
+            const uint32_t nblocks = (vc.spp + AEHIP_SAMPLE_BLOCK - 1u) / AEHIP_SAMPLE_BLOCK;
+            func = reinterpret_cast<const void *>(path_stream_exact_kernel);
+            for(uint32_t blk = 0; blk < nblocks; blk++) {
+                const uint32_t begin = blk * AEHIP_SAMPLE_BLOCK;
+                const uint32_t count = std::min(AEHIP_SAMPLE_BLOCK, vc.spp - begin);
+                AEHIP_CHECK(hipMemsetAsync(b->d_rays + 2, 0, sizeof(unsigned long long), stream));
+                hipLaunchKernelGGL(path_stream_exact_kernel, dim3(groups), dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind,
+                                   b->d_sample_terms, b->d_radiance, begin, count, b->d_rays, reinterpret_cast<uint32_t *>(b->d_rays + 2));
+                hipLaunchKernelGGL(resolve_block_kernel, dim3((strips + 3u) / 4u), dim3(kBlock), 0, stream, vc, b->d_radiance, b->d_totals,
+                                   count, blk == 0 ? 1u : 0u, blk + 1 == nblocks ? 1u : 0u, argb_dev, rgba);
+            }
         } else if(exact) {
             if(list == kListLdsOnce) AEHIP_LAUNCH_PATH(true, kListLdsOnce);
             else if(list == kListLdsChunked) AEHIP_LAUNCH_PATH(true, kListLdsChunked);
@@ -1499,6 +1688,8 @@ void aehip_backend_destroy(aehip_backend *b) {
     if(b->d_argb) (void)hipFree(b->d_argb);
     if(b->d_rays) (void)hipFree(b->d_rays);
     if(b->d_sample_terms) (void)hipFree(b->d_sample_terms);
+    if(b->d_radiance) (void)hipFree(b->d_radiance);
+    if(b->d_totals) (void)hipFree(b->d_totals);
     if(b->h_staging) (void)hipHostFree(b->h_staging);
     if(b->ev_begin) (void)hipEventDestroy(b->ev_begin);
     if(b->ev_end) (void)hipEventDestroy(b->ev_end);
@@ -1642,6 +1833,38 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
         if(e == hipSuccess) e = hipStreamSynchronize(b->stream);
         std::free(geom); std::free(matl); std::free(kind);
         if(e != hipSuccess) return fail(AEHIP_E_HIP, "scene upload: %s", hipGetErrorString(e));
+    }
+
+    // buffers of the exact streamed pass (see launch()): a block of per-path radiance and the
+    // per-pixel totals; scenes it does not serve, or images beyond the memory budget, keep the
+    // per-lane pass
+    {
+        const bool wanted = !(p.flags & AEHIP_FLAG_FAST) && p.pass == AEHIP_PASS_PATH && p.list_source != 1u &&
+                            !(p.flags & AEHIP_FLAG_NO_REGEN) && vc.n_spheres >= kPoolMinSpheres && p.max_depth > 1 &&
+                            !(b->all_terminal && vc.n_spheres <= static_cast<uint32_t>(kLdsSpheres));
+        const size_t strips = static_cast<size_t>((p.width + kTileW - 1) / kTileW) * ((p.row_count + 3u) / 4u);
+        const size_t need = strips * 64u * AEHIP_SAMPLE_BLOCK;
+        const size_t pixels = static_cast<size_t>(p.width) * p.row_count;
+        constexpr size_t kBudget = (static_cast<size_t>(32) << 30) / sizeof(radiance3);       // 32 GiB
+        if(!wanted || need > kBudget) {
+            if(b->d_radiance) (void)hipFree(b->d_radiance);
+            if(b->d_totals) (void)hipFree(b->d_totals);
+            b->d_radiance = nullptr; b->d_totals = nullptr;
+            b->radiance_capacity = 0; b->totals_capacity = 0;
+        } else {
+            if(need > b->radiance_capacity) {
+                if(b->d_radiance) (void)hipFree(b->d_radiance);
+                b->d_radiance = nullptr; b->radiance_capacity = 0;
+                AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_radiance), need * sizeof(radiance3)));
+                b->radiance_capacity = need;
+            }
+            if(pixels > b->totals_capacity) {
+                if(b->d_totals) (void)hipFree(b->d_totals);
+                b->d_totals = nullptr; b->totals_capacity = 0;
+                AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_totals), pixels * sizeof(radiance3)));
+                b->totals_capacity = pixels;
+            }
+        }
     }
 
     // per-sample key terms

@@ -131,6 +131,8 @@ CASES = {
     "camera_inside_sphere": dict(size=(64, 64), spp=4, max_depth=1, seed=2, jitter=True, spheres=None, cam=(0.1, 0.0, -1.6)),
     "grazing_depth20": dict(size=(128, 96), spp=8, max_depth=20, seed=13, jitter=True, spheres="grazing"),
     "stress_depth6": dict(size=(64, 40), spp=3, max_depth=6, seed=4, jitter=True, spheres="stress3000"),
+    # more than one block of 64 samples, ragged size: the exact streamed pass's launch pair per block
+    "divergence_two_blocks": dict(size=(50, 30), spp=70, max_depth=12, seed=21, jitter=True, spheres="divergence"),
 }
 LIST_SOURCES = {"scalar": 0, "lds": 1}
 
@@ -321,6 +323,33 @@ def test_streamed_fast_pass_traces_the_same_paths_as_the_per_lane_pass(size, spp
     assert st_stream.rays / st_stream.lane_slots > st_lane.rays / st_lane.lane_slots
     if w * h > 1_000_000:
         assert st_stream.rays / st_stream.lane_slots >= 0.8        # 0.84 measured at 8 spp, 0.93 at 16, 0.99 at 64
+
+
+def test_streamed_exact_pass_equals_the_per_lane_pass_at_1080p():
+    """The exact build streams strips to persistent waves too (radiance per path in a buffer, summed
+    in the specified order by a second kernel).  At 1080p there are four times more strips than
+    the chip holds waves.  Bit-identical to the one-lane-per-pixel pass, which the small cases pin
+    to the oracle."""
+    sph = scenes.divergence_scene()
+    w, h = 1920, 1080
+    a_argb, a_rgba, st_a = render_device(w, h, spp=2, max_depth=50, seed=7, jitter=True, spheres=sph, count_rays=True)
+    back = rt.HipRaytracer(None)
+    import torch
+
+    try:
+        f = rt.FLAG_JITTER | rt.FLAG_COUNT_RAYS | rt.FLAG_NO_REGEN
+        assert back.setup(w, h, 2, 50, 7, f, rt.PASS_PATH, spheres=sph)
+        argb = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+        rgba = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        back.trace_device(argb.data_ptr(), rgba.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        st_b = back.stats()
+        np.testing.assert_array_equal(a_argb, argb.cpu().numpy().view(np.uint32))
+        np.testing.assert_array_equal(a_rgba.view(np.uint32), rgba.cpu().numpy().view(np.uint32))
+    finally:
+        back.close()
+    assert st_a.rays == st_b.rays
+    assert st_a.rays / st_a.lane_slots > 1.5 * st_b.rays / st_b.lane_slots
 
 
 # ------------------------------------------------------------------ one frame on several devices
