@@ -706,226 +706,65 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
 }
 
 // ------------------------------------------------------------------------------------------
-// streamed path pass (fast build): the wave, not the lane, owns pixels, and persistent waves
-// take pixel strips from a queue.
+// streamed path pass: the wave, not the lane, owns pixels, and persistent waves take work units
+// from a queue.
 //
-// A 16x4 pixel strip times spp samples is a pool of 64*spp work items; item i is sample i/64 of
-// pixel i%64, so the first 64 items are the strip's coherent first samples.  Whenever lanes
-// finish their paths, a ballot counts them and the next items of the pool are dealt out in lane
-// order (prefix popcount of the ballot; the pool cursor is wave-uniform), so lanes stay busy
-// whatever the spread of path lengths -- with one lane per pixel (path_kernel) a lane whose
-// pixel is finished idles until its wave's slowest pixel is.  Finished paths add their radiance
-// to per-pixel fixed-point accumulators in LDS (ds_add_u64: the sum does not depend on the order
-// of additions); lane l resolves pixel l when the strip's last path has ended.
+// A unit is a 16x4 pixel strip times a chunk of up to kChunkSamples samples: a pool of 64*chunk
+// work items; item i is sample i/64 of pixel i%64, so an item row is the strip's 64 coherent
+// pixels.  Whenever lanes finish their paths, a ballot counts them and the next items of the pool
+// are dealt out in lane order (prefix popcount of the ballot; the pool cursor is wave-uniform),
+// so lanes stay busy whatever the spread of path lengths -- with one lane per pixel (path_kernel)
+// a lane whose pixel is finished idles until its wave's slowest pixel is.
 //
-// A wave does not end with its strip: that would idle lanes while each pool drains (its last,
+// A wave does not end with its unit: that would idle lanes while each pool drains (its last,
 // longest paths) and, per launch, while the last and heaviest waves finish on an emptying chip.
-// Strips are numbered row-major; a wave takes the next one from a global counter when its
-// current pool is dealt out, and deals the new strip's items to lanes as they come free while
-// other lanes are still finishing paths of the previous strip.  Two accumulator sets in LDS
-// (current and previous strip) alternate; a set is resolved when the last path of its strip has
-// ended, counted with ballots.  A wave leaves when the queue is empty and its own paths are
-// done -- it never waits for another wave -- so lanes idle only in a wave's very last paths,
-// and the launch needs no more waves than the chip holds.  Measured on the depth-50
-// mixed-material scene: 93-99 % of lane slots trace a ray (76 % with one strip per wave, 24 %
-// without regeneration).
+// Units are numbered strip-major; a wave takes the next one from a global counter when its
+// current pool is dealt out, and deals the new unit's items to lanes as they come free while
+// other lanes are still finishing paths of earlier units.  A wave leaves when the queue is empty
+// and its own paths are done -- it never waits for another wave -- so lanes idle only in a
+// wave's very last paths, and the launch needs no more waves than the chip holds.  Chunks keep
+// a strip over a glass sphere from pinning one wave for the whole launch: its samples are spread
+// over several waves.  Measured on the depth-50 mixed-material scene: 93-99 % of lane slots trace
+// a ray (76 % with one strip per wave, 57 % with per-lane regeneration, 24 % without).
 //
-// The fixed-point sum is not the specified float sum, so this pass serves the fast build only;
-// the exact build keeps per-lane sums in the specified order (path_kernel).
-// ------------------------------------------------------------------------------------------
-
-__global__ __launch_bounds__(kBlock) void path_stream_kernel(view_consts vc, const float4 *__restrict__ geom,
-                                                             const float4 *__restrict__ matl,
-                                                             const uint32_t *__restrict__ kind,
-                                                             const uint32_t *__restrict__ sample_terms,
-                                                             uint32_t *__restrict__ argb, float4 *__restrict__ rgba,
-                                                             unsigned long long *ray_counter, uint32_t *strip_queue) {
-    constexpr int kWaves = kBlock / 64;
-    // per-pixel sums in fixed point (2^-24 units in 64 bits): integer addition is associative, so
-    // the image does not depend on the order in which paths happen to finish
-    __shared__ unsigned long long s_acc[kWaves][2][3][64];
-    __shared__ uint32_t s_term[kWaves][2][64];       // per-pixel key terms of the two strips
-    constexpr float kFixedScale = 16777216.0f;       // 2^24
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
-    const uint32_t strips_x = (vc.width + kTileW - 1) / kTileW;
-    const uint32_t strips_y = (vc.row_count + 3u) / 4u;
-    const uint32_t n_strips = strips_x * strips_y;
-    const uint32_t pool = 64u * vc.spp;              // items of one strip
-
-    // wave-uniform state
-    uint32_t cur = 1;                                // accumulator set of the strip being dealt
-    uint32_t cursor = pool;                          // next undealt item of that strip (pool = none left)
-    bool queue_empty = false;
-    bool active[2] = {false, false};                 // the set holds a strip with unfinished items
-    uint32_t done[2] = {0, 0};                       // finished items of the set's strip
-    uint32_t strip_x0[2] = {0, 0}, strip_row0[2] = {0, 0};
-
-    // lane state
-    uint32_t nrays = 0, iterations = 0;
-    uint32_t pix = 0, lset = 0, y = 0;
-    bool tracing = false;
-    path_state ps;
-    ps.o = ps.d = ps.thr = f3{0.0f, 0.0f, 0.0f};
-    ps.rng = 0;
-    ps.bounce = 0;
-
-    // writes the pixels of a finished strip (lane l owns pixel l)
-    auto resolve = [&](uint32_t set) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t x = strip_x0[set] + (lane & 15u);
-        const uint32_t row = strip_row0[set] + (lane >> 4);
-        if(x < vc.width && row < vc.row_count) {
-            const float n = static_cast<float>(vc.spp);     // true division, as in the other passes
-            const float r = clamp01(static_cast<float>(s_acc[wave][set][0][lane]) * (1.0f / kFixedScale) / n);
-            const float g = clamp01(static_cast<float>(s_acc[wave][set][1][lane]) * (1.0f / kFixedScale) / n);
-            const float b = clamp01(static_cast<float>(s_acc[wave][set][2][lane]) * (1.0f / kFixedScale) / n);
-            const size_t idx = static_cast<size_t>(row) * vc.width + x;
-            argb[idx] = pack_argb32(r, g, b);
-            if(rgba) rgba[idx] = make_float4(r, g, b, 1.0f);
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
-
-    for(;;) {
-        const unsigned long long want = __ballot(!tracing);
-        if(want != 0ull) {
-            // out of items: take the next strip if the other accumulator set is free
-            if(cursor >= pool && !queue_empty && !active[cur ^ 1u]) {
-                uint32_t id = 0;
-                if(lane == 0) id = atomicAdd(strip_queue, 1u);
-                id = __builtin_amdgcn_readfirstlane(id);
-                if(id >= n_strips) {
-                    queue_empty = true;
-                } else {
-                    cur ^= 1u;
-                    const uint32_t sy = id / strips_x;
-                    strip_x0[cur] = (id - sy * strips_x) * kTileW;
-                    strip_row0[cur] = sy * 4u;
-                    active[cur] = true;
-                    done[cur] = 0;
-                    cursor = 0;
-                    s_acc[wave][cur][0][lane] = 0ull;
-                    s_acc[wave][cur][1][lane] = 0ull;
-                    s_acc[wave][cur][2][lane] = 0ull;
-                    s_term[wave][cur][lane] = pixel_term(vc.seed_hash, image_row(vc, strip_row0[cur] + (lane >> 4)) * vc.width +
-                                                                            strip_x0[cur] + (lane & 15u));
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-            // deal the strip's next items to the free lanes, in lane order
-            if(cursor < pool) {
-                const uint32_t before = __builtin_popcountll(want & ((1ull << lane) - 1ull));
-                const uint32_t item = cursor + before;
-                const uint32_t dealt = min(static_cast<uint32_t>(__builtin_popcountll(want)), pool - cursor);
-                cursor += dealt;
-                bool outside = false;
-                if(!tracing && item < pool) {
-                    pix = item & 63u;
-                    const uint32_t sample = item >> 6;
-                    const uint32_t x = strip_x0[cur] + (pix & 15u);
-                    const uint32_t row = strip_row0[cur] + (pix >> 4);
-                    if(x < vc.width && row < vc.row_count) {
-                        y = image_row(vc, row);
-                        lset = cur;
-                        start_path<false>(vc, s_term[wave][cur][pix], sample_terms, x, y, sample, ps);
-                        tracing = true;
-                    } else {
-                        outside = true;             // item of a pixel outside the image: nothing to trace
-                    }
-                }
-                done[cur] += static_cast<uint32_t>(__builtin_popcountll(__ballot(outside)));
-            }
-        }
-
-        if(__any(tracing)) {
-            iterations++;
-            float closest = 3.402823466e+38f;
-            int hit = -1;
-            bool ended = false;
-            if(tracing) {
-                intersect_chunk<false>(geom, vc.n_spheres, 0, ps.o, ps.d, 2.0f, 4.0f, closest, hit);
-                nrays++;
-                f3 L;
-                if(shade_segment<false>(vc, y, hit, closest, geom, matl, kind, ps, L)) {
-                    if(L.x != 0.0f || L.y != 0.0f || L.z != 0.0f) {
-                        // radiance beyond 255 saturates (reflectances are at most 1 in a sane scene)
-                        const float top = 4294967040.0f;
-                        atomicAdd(&s_acc[wave][lset][0][pix], static_cast<unsigned long long>(__float2uint_rn(fminf(L.x * kFixedScale, top))));
-                        atomicAdd(&s_acc[wave][lset][1][pix], static_cast<unsigned long long>(__float2uint_rn(fminf(L.y * kFixedScale, top))));
-                        atomicAdd(&s_acc[wave][lset][2][pix], static_cast<unsigned long long>(__float2uint_rn(fminf(L.z * kFixedScale, top))));
-                    }
-                    tracing = false;
-                    ended = true;
-                }
-            }
-            done[0] += static_cast<uint32_t>(__builtin_popcountll(__ballot(ended && lset == 0u)));
-            done[1] += static_cast<uint32_t>(__builtin_popcountll(__ballot(ended && lset == 1u)));
-        }
-
-#pragma unroll
-        for(uint32_t set = 0; set < 2; set++) {
-            if(active[set] && done[set] >= pool) {
-                resolve(set);
-                active[set] = false;
-            }
-        }
-        if(queue_empty && !active[0] && !active[1]) break;
-    }
-
-    if(vc.flags & AEHIP_FLAG_COUNT_RAYS) {
-        uint32_t v = nrays;
-#pragma unroll
-        for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if(lane == 0) {
-            atomicAdd(ray_counter, static_cast<unsigned long long>(v));
-            atomicAdd(ray_counter + 1, 64ull * iterations);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// streamed path pass, exact build.
-//
-// The exact build must add a pixel's samples in the specified order, so finished paths cannot be
-// accumulated as they come.  Instead each path's radiance is stored under its (pixel, sample) in
-// a device buffer, one block of up to AEHIP_SAMPLE_BLOCK samples per launch, and a second kernel
+// Where the radiance goes: samples must be added in the specified order (exact build), and the
+// image should not depend on which wave finished what first (fast build), so finished paths are
+// not accumulated as they come.  Each path's radiance is stored under its (pixel, sample) in a
+// device buffer, one block of up to AEHIP_SAMPLE_BLOCK samples per launch, and a second kernel
 // adds the block's samples in sample order and the block sums in block order.  The tracing
-// kernel then has no per-strip state at all beyond the dealing cursor: persistent waves take
-// strip after strip from the queue and deal each strip's items to whichever lanes are free, as in
-// the fast build, and any number of strips can be in flight in one wave.  The buffer costs 12
-// bytes per path of HBM traffic each way -- nothing beside the tracing -- and 768 bytes per pixel
-// of memory for blocks of 64.
+// kernel therefore keeps no per-strip state beyond the dealing cursor.  The buffer costs 12 bytes
+// per path of HBM traffic each way -- nothing beside the tracing -- and 768 bytes per pixel of
+// memory.
 // ------------------------------------------------------------------------------------------
+
+constexpr uint32_t kChunkSamples = 4;        // samples of a strip that one queue unit covers (256 items; measured best of 1..16)
 
 struct radiance3 {
     float r, g, b;
 };
 
-__global__ __launch_bounds__(kBlock) void path_stream_exact_kernel(view_consts vc, const float4 *__restrict__ geom,
-                                                                   const float4 *__restrict__ matl,
-                                                                   const uint32_t *__restrict__ kind,
-                                                                   const uint32_t *__restrict__ sample_terms,
-                                                                   radiance3 *__restrict__ radiance, uint32_t sample_begin,
-                                                                   uint32_t sample_count, unsigned long long *ray_counter,
-                                                                   uint32_t *strip_queue) {
+template <bool EXACT>
+__global__ __launch_bounds__(kBlock) void path_stream_kernel(view_consts vc, const float4 *__restrict__ geom,
+                                                             const float4 *__restrict__ matl,
+                                                             const uint32_t *__restrict__ kind,
+                                                             const uint32_t *__restrict__ sample_terms,
+                                                             radiance3 *__restrict__ radiance, uint32_t sample_begin,
+                                                             uint32_t sample_count, unsigned long long *ray_counter,
+                                                             uint32_t *unit_queue) {
     constexpr int kWaves = kBlock / 64;
-    __shared__ uint32_t s_term[kWaves][64];          // per-pixel key terms of the strip being dealt
+    __shared__ uint32_t s_term[kWaves][64];          // per-pixel key terms of the unit being dealt
 
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     const uint32_t strips_x = (vc.width + kTileW - 1) / kTileW;
     const uint32_t strips_y = (vc.row_count + 3u) / 4u;
-    const uint32_t n_strips = strips_x * strips_y;
-    const uint32_t pool = 64u * sample_count;        // items of one strip in this launch
+    const uint32_t chunks = (sample_count + kChunkSamples - 1u) / kChunkSamples;     // units per strip
+    const uint32_t n_units = strips_x * strips_y * chunks;
 
     // wave-uniform state
-    uint32_t cursor = pool;                          // next undealt item of the current strip (pool = none left)
+    uint32_t pool = 0, cursor = 0;                   // items of the current unit, next undealt one (cursor == pool: none left)
     bool queue_empty = false;
-    uint32_t strip = 0, strip_x0 = 0, strip_row0 = 0;
+    uint32_t strip = 0xffffffffu, strip_x0 = 0, strip_row0 = 0, chunk_begin = 0;      // no strip yet
 
     // lane state
     uint32_t nrays = 0, iterations = 0;
@@ -942,20 +781,25 @@ __global__ __launch_bounds__(kBlock) void path_stream_exact_kernel(view_consts v
         if(want != 0ull) {
             if(cursor >= pool && !queue_empty) {
                 uint32_t id = 0;
-                if(lane == 0) id = atomicAdd(strip_queue, 1u);
+                if(lane == 0) id = atomicAdd(unit_queue, 1u);
                 id = __builtin_amdgcn_readfirstlane(id);
-                if(id >= n_strips) {
+                if(id >= n_units) {
                     queue_empty = true;
                 } else {
-                    strip = id;
-                    const uint32_t sy = id / strips_x;
-                    strip_x0 = (id - sy * strips_x) * kTileW;
-                    strip_row0 = sy * 4u;
+                    const uint32_t new_strip = id / chunks;
+                    chunk_begin = (id - new_strip * chunks) * kChunkSamples;
+                    pool = 64u * min(kChunkSamples, sample_count - chunk_begin);
                     cursor = 0;
-                    __builtin_amdgcn_wave_barrier();
-                    s_term[wave][lane] = pixel_term(vc.seed_hash, image_row(vc, strip_row0 + (lane >> 4)) * vc.width + strip_x0 + (lane & 15u));
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
+                    if(new_strip != strip) {
+                        strip = new_strip;
+                        const uint32_t sy = strip / strips_x;
+                        strip_x0 = (strip - sy * strips_x) * kTileW;
+                        strip_row0 = sy * 4u;
+                        __builtin_amdgcn_wave_barrier();
+                        s_term[wave][lane] = pixel_term(vc.seed_hash, image_row(vc, strip_row0 + (lane >> 4)) * vc.width + strip_x0 + (lane & 15u));
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
             }
             if(cursor < pool) {
@@ -964,13 +808,13 @@ __global__ __launch_bounds__(kBlock) void path_stream_exact_kernel(view_consts v
                 cursor += min(static_cast<uint32_t>(__builtin_popcountll(want)), pool - cursor);
                 if(!tracing && item < pool) {
                     const uint32_t pix = item & 63u;
-                    const uint32_t local = item >> 6;
+                    const uint32_t local = chunk_begin + (item >> 6);           // sample within the block
                     const uint32_t x = strip_x0 + (pix & 15u);
                     const uint32_t row = strip_row0 + (pix >> 4);
                     if(x < vc.width && row < vc.row_count) {
                         y = image_row(vc, row);
                         slot = (static_cast<size_t>(strip) * AEHIP_SAMPLE_BLOCK + local) * 64u + pix;
-                        start_path<true>(vc, s_term[wave][pix], sample_terms, x, y, sample_begin + local, ps);
+                        start_path<EXACT>(vc, s_term[wave][pix], sample_terms, x, y, sample_begin + local, ps);
                         tracing = true;
                     }
                     // an item of a pixel outside the image is simply dropped
@@ -980,17 +824,22 @@ __global__ __launch_bounds__(kBlock) void path_stream_exact_kernel(view_consts v
 
         if(!__any(tracing)) {
             if(queue_empty && cursor >= pool) break;
-            continue;               // only out-of-image items were dealt, or the next strip is due
+            continue;               // only out-of-image items were dealt, or the next unit is due
         }
         iterations++;
         if(tracing) {
-            const float a = dot3<true>(ps.d, ps.d);
+            float a2 = 2.0f, a4 = 4.0f;
+            if constexpr(EXACT) {
+                const float a = dot3<true>(ps.d, ps.d);     // ~1, not assumed 1 (src/shapes.cpp:16)
+                a2 = 2.0f * a;
+                a4 = 4.0f * a;
+            }
             float closest = 3.402823466e+38f;
             int hit = -1;
-            intersect_chunk<true>(geom, vc.n_spheres, 0, ps.o, ps.d, 2.0f * a, 4.0f * a, closest, hit);
+            intersect_chunk<EXACT>(geom, vc.n_spheres, 0, ps.o, ps.d, a2, a4, closest, hit);
             nrays++;
             f3 L;
-            if(shade_segment<true>(vc, y, hit, closest, geom, matl, kind, ps, L)) {
+            if(shade_segment<EXACT>(vc, y, hit, closest, geom, matl, kind, ps, L)) {
                 radiance[slot] = radiance3{L.x, L.y, L.z};
                 tracing = false;
             }
@@ -1481,7 +1330,7 @@ struct aehip_backend {
     unsigned long long *d_rays = nullptr;    // ray segments, lane slots, strip queue of the streamed pass
     uint32_t *d_sample_terms = nullptr;      // spp + 1 words: per-sample key terms (+1 spare for prefetch)
     uint32_t sample_terms_capacity = 0;
-    radiance3 *d_radiance = nullptr;         // exact streamed pass: one block of per-path radiance
+    radiance3 *d_radiance = nullptr;         // streamed pass: one block of per-path radiance
     radiance3 *d_totals = nullptr;           //   and the per-pixel sums of finished blocks
     size_t radiance_capacity = 0, totals_capacity = 0;   // in elements
 
@@ -1562,34 +1411,30 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         // The streamed pass pays a few LDS operations per path; it wins once a segment costs more
         // than that, i.e. for all but the smallest shape lists.
         // (Paths of one segment all end together: nothing to stream, the per-lane pass is leaner.)
-        if(!exact && list == kListScalar && !(vc.flags & AEHIP_FLAG_NO_REGEN) && vc.n_spheres >= kPoolMinSpheres && vc.max_depth > 1) {
+        if(list == kListScalar && !(vc.flags & AEHIP_FLAG_NO_REGEN) && vc.n_spheres >= kPoolMinSpheres && vc.max_depth > 1 &&
+           b->d_radiance != nullptr) {
             // persistent waves: no more workgroups than the chip holds at once (a larger grid
-            // would be just as correct -- late waves would find the queue empty)
+            // would be just as correct -- late waves would find the queue empty); one launch
+            // pair per block of samples
             int per_cu = 0;
-            AEHIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_stream_kernel, kBlock, 0));
+            if(exact) AEHIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_stream_kernel<true>, kBlock, 0));
+            else AEHIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_stream_kernel<false>, kBlock, 0));
             const uint32_t strips = ((vc.width + kTileW - 1) / kTileW) * ((vc.row_count + 3u) / 4u);
             const uint32_t resident = static_cast<uint32_t>(per_cu > 0 ? per_cu : 1) * static_cast<uint32_t>(b->cu_count);
-            const uint32_t groups = std::min(resident, (strips + 3u) / 4u);
-            AEHIP_CHECK(hipMemsetAsync(b->d_rays + 2, 0, sizeof(unsigned long long), stream));
-            func = reinterpret_cast<const void *>(path_stream_kernel);
-            hipLaunchKernelGGL(path_stream_kernel, dim3(groups), dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind,
-                               b->d_sample_terms, argb_dev, rgba, b->d_rays, reinterpret_cast<uint32_t *>(b->d_rays + 2));
-        } else if(exact && list == kListScalar && !(vc.flags & AEHIP_FLAG_NO_REGEN) && vc.n_spheres >= kPoolMinSpheres && vc.max_depth > 1 &&
-                  b->d_radiance != nullptr) {
-            // exact build, streamed: one launch pair per block of samples
-            int per_cu = 0;
-            AEHIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_stream_exact_kernel, kBlock, 0));
-            const uint32_t strips = ((vc.width + kTileW - 1) / kTileW) * ((vc.row_count + 3u) / 4u);
-            const uint32_t resident = static_cast<uint32_t>(per_cu > 0 ? per_cu : 1) * static_cast<uint32_t>(b->cu_count);
-            const uint32_t groups = std::min(resident, (strips + 3u) / 4u);
             const uint32_t nblocks = (vc.spp + AEHIP_SAMPLE_BLOCK - 1u) / AEHIP_SAMPLE_BLOCK;
-            func = reinterpret_cast<const void *>(path_stream_exact_kernel);
+            func = exact ? reinterpret_cast<const void *>(path_stream_kernel<true>) : reinterpret_cast<const void *>(path_stream_kernel<false>);
             for(uint32_t blk = 0; blk < nblocks; blk++) {
                 const uint32_t begin = blk * AEHIP_SAMPLE_BLOCK;
                 const uint32_t count = std::min(AEHIP_SAMPLE_BLOCK, vc.spp - begin);
+                const uint64_t units = static_cast<uint64_t>(strips) * ((count + kChunkSamples - 1u) / kChunkSamples);
+                const uint32_t groups = static_cast<uint32_t>(std::min<uint64_t>(resident, (units + 3u) / 4u));
                 AEHIP_CHECK(hipMemsetAsync(b->d_rays + 2, 0, sizeof(unsigned long long), stream));
-                hipLaunchKernelGGL(path_stream_exact_kernel, dim3(groups), dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind,
-                                   b->d_sample_terms, b->d_radiance, begin, count, b->d_rays, reinterpret_cast<uint32_t *>(b->d_rays + 2));
+                if(exact)
+                    hipLaunchKernelGGL(path_stream_kernel<true>, dim3(groups), dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind,
+                                       b->d_sample_terms, b->d_radiance, begin, count, b->d_rays, reinterpret_cast<uint32_t *>(b->d_rays + 2));
+                else
+                    hipLaunchKernelGGL(path_stream_kernel<false>, dim3(groups), dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind,
+                                       b->d_sample_terms, b->d_radiance, begin, count, b->d_rays, reinterpret_cast<uint32_t *>(b->d_rays + 2));
                 hipLaunchKernelGGL(resolve_block_kernel, dim3((strips + 3u) / 4u), dim3(kBlock), 0, stream, vc, b->d_radiance, b->d_totals,
                                    count, blk == 0 ? 1u : 0u, blk + 1 == nblocks ? 1u : 0u, argb_dev, rgba);
             }
@@ -1835,11 +1680,11 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
         if(e != hipSuccess) return fail(AEHIP_E_HIP, "scene upload: %s", hipGetErrorString(e));
     }
 
-    // buffers of the exact streamed pass (see launch()): a block of per-path radiance and the
+    // buffers of the streamed pass (see launch()): a block of per-path radiance and the
     // per-pixel totals; scenes it does not serve, or images beyond the memory budget, keep the
     // per-lane pass
     {
-        const bool wanted = !(p.flags & AEHIP_FLAG_FAST) && p.pass == AEHIP_PASS_PATH && p.list_source != 1u &&
+        const bool wanted = p.pass == AEHIP_PASS_PATH && p.list_source != 1u &&
                             !(p.flags & AEHIP_FLAG_NO_REGEN) && vc.n_spheres >= kPoolMinSpheres && p.max_depth > 1 &&
                             !(b->all_terminal && vc.n_spheres <= static_cast<uint32_t>(kLdsSpheres));
         const size_t strips = static_cast<size_t>((p.width + kTileW - 1) / kTileW) * ((p.row_count + 3u) / 4u);
