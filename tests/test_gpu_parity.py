@@ -364,11 +364,11 @@ def test_trace_frame_is_independent_of_the_number_of_bands(bands):
     assert sha(img) == want
     assert st.paths == 1920 * 1080
 
-    sph = scenes.showcase_scene()
-    whole, _ = rt.render(130, 75, spp=3, max_depth=6, seed=9, jitter=True, spheres=sph, count_rays=True)
-    split, st = rt.trace_frame(bands, 130, 75, spp=3, max_depth=6, seed=9, jitter=True, spheres=sph, count_rays=True)
-    np.testing.assert_array_equal(split, whole)
-    assert st.paths == 130 * 75 * 3 and st.rays > st.paths
+    for sph in (scenes.showcase_scene(), scenes.divergence_scene()):       # per-lane pass, streamed pass
+        whole, _ = rt.render(130, 75, spp=3, max_depth=6, seed=9, jitter=True, spheres=sph, count_rays=True)
+        split, st = rt.trace_frame(bands, 130, 75, spp=3, max_depth=6, seed=9, jitter=True, spheres=sph, count_rays=True)
+        np.testing.assert_array_equal(split, whole)
+        assert st.paths == 130 * 75 * 3 and st.rays > st.paths
 
 
 def test_trace_frame_rejects_more_bands_than_rows():
@@ -436,12 +436,13 @@ def test_tiled_bands_equal_the_whole_image(world, tile_rows, size):
     for fast in (False, True):
         whole_d, _ = rt.render(w, h, spp=8, max_depth=8, seed=3, jitter=True, fast=fast)
         np.testing.assert_array_equal(render_tiled(w, h, world, tile_rows, spp=8, max_depth=8, seed=3, jitter=True, fast=fast), whole_d)
-    # fast build, streamed pass (>= 16 spheres): fixed-point pixel sums, independent of the order
-    # in which paths finish and so of the launch's shape
+    # streamed pass (>= 16 spheres), both builds: per-path radiance summed in the specified order,
+    # independent of the order in which paths finish and so of the launch's shape
     many = scenes.divergence_scene()
-    whole_f, _ = rt.render(w, h, spp=4, max_depth=6, seed=9, jitter=True, fast=True, spheres=many)
-    tiled_f = render_tiled(w, h, world, tile_rows, spp=4, max_depth=6, seed=9, jitter=True, fast=True, spheres=many)
-    np.testing.assert_array_equal(tiled_f, whole_f)
+    for fast in (True, False):
+        whole_s, _ = rt.render(w, h, spp=5, max_depth=6, seed=9, jitter=True, fast=fast, spheres=many)
+        tiled_s = render_tiled(w, h, world, tile_rows, spp=5, max_depth=6, seed=9, jitter=True, fast=fast, spheres=many)
+        np.testing.assert_array_equal(tiled_s, whole_s)
 
 
 def test_setup_rejects_bad_tile_requests():
