@@ -89,7 +89,7 @@ def cpu_baseline(target_seconds: float):
     out = {
         "value": WIDTH * HEIGHT * spp / (ms * 1e-3) / 1e6,
         "unit": "Mpaths/s",
-        "cores": threads,
+        "cores": threads, "host_cpus_online": os.cpu_count(),
         "kind": "port",
         "sample": f"{WIDTH}x{HEIGHT} default scene, {spp} of 1024 spp, jittered, row-parallel CPU oracle, {ms * 1e-3:.1f} s",
     }
