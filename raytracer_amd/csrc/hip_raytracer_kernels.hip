@@ -925,8 +925,7 @@ template <bool EXACT, bool ONE, bool FOLD, bool AXIAL>
 __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_consts cc, uint32_t split_log2,
                                                         const float4 *__restrict__ geom,
                                                         const uint32_t *__restrict__ sample_terms,
-                                                        uint32_t *__restrict__ argb, float4 *__restrict__ rgba,
-                                                        unsigned long long *ray_counter) {
+                                                        uint32_t *__restrict__ argb, float4 *__restrict__ rgba) {
     constexpr uint32_t kWaves = kBlock / 64;
     __shared__ float4 s_occ[ONE ? 1 : kLdsSpheres];     // oc.xyz, c
     __shared__ float4 s_ctr[ONE ? 1 : kLdsSpheres];     // centre.xyz, oc.oc + r*r
@@ -1002,7 +1001,6 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
     }
 
     f3 sum = {0.0f, 0.0f, 0.0f};
-    uint32_t my_samples = 0;            // samples this wave traces per pixel (wave-uniform)
 
     if constexpr(EXACT) {
         // the sample's ray exactly as the reference builds it (src/software_raytracer.cpp:218-221)
@@ -1020,7 +1018,6 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
             if(blk < nblocks) {
                 const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
                 const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
-                my_samples += s1 - s0;
                 uint32_t term = sample_terms[s0];
                 if(valid) {
                     for(uint32_t sample = s0; sample < s1; sample++) {
@@ -1141,7 +1138,6 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
         for(uint32_t blk = part; blk < nblocks; blk += split) {
             const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
             const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
-            my_samples += s1 - s0;
             uint32_t term = sample_terms[s0];
             if(valid) {
                 // unrolled: with 8 vector instructions per missing sample the loop's own scalar
@@ -1269,16 +1265,8 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
         if(rgba) rgba[idx] = make_float4(r, g, b, 1.0f);
     }
 
-    if(vc.flags & AEHIP_FLAG_COUNT_RAYS) {
-        uint32_t v = valid ? my_samples : 0u;
-        const bool wave_has_work = __any(valid);
-#pragma unroll
-        for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if(lane == 0) {
-            atomicAdd(ray_counter, static_cast<unsigned long long>(v));
-            atomicAdd(ray_counter + 1, wave_has_work ? 64ull * my_samples : 0ull);
-        }
-    }
+    // (Ray and lane-slot counts of this pass follow from the image size -- one ray per sample,
+    // every lane of a strip busy for each of its samples -- and are filled in by the host.)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1339,6 +1327,8 @@ struct aehip_backend {
     bool timed_on_own_stream = false;
     const void *attr_func = nullptr;         // kernel whose resource figures are in stats
     aehip_stats stats{};
+    bool counts_known = false;               // the last launch's ray / lane-slot counts follow from its shape
+    uint64_t known_rays = 0, known_lane_slots = 0;
 };
 
 namespace {
@@ -1350,6 +1340,7 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
     const void *func = nullptr;
 
     if(vc.flags & AEHIP_FLAG_COUNT_RAYS) AEHIP_CHECK(hipMemsetAsync(b->d_rays, 0, 2 * sizeof(unsigned long long), stream));
+    b->counts_known = false;
 
     if(b->params.pass == AEHIP_PASS_PRIMARY) {
         const bool vec4 = (vc.width % 4u) == 0 && (reinterpret_cast<uintptr_t>(argb_dev) % 16u) == 0;
@@ -1379,8 +1370,12 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
     do {                                                                                                               \
         func = reinterpret_cast<const void *>(camera_kernel<E, O, F, A>);                                              \
         hipLaunchKernelGGL((camera_kernel<E, O, F, A>), grid, dim3(kBlock), 0, stream, vc, b->cc, split_log2,          \
-                           b->d_geom, b->d_sample_terms, argb_dev, rgba, b->d_rays);                                   \
+                           b->d_geom, b->d_sample_terms, argb_dev, rgba);                                              \
     } while(0)
+        // one ray per sample; a strip's 64 lanes run for each of its samples
+        b->counts_known = true;
+        b->known_rays = static_cast<uint64_t>(vc.width) * vc.row_count * vc.spp;
+        b->known_lane_slots = static_cast<uint64_t>((vc.width + kTileW - 1) / kTileW) * ((vc.row_count + 3u) / 4u) * 64u * vc.spp;
         // the quadratic's cross term vanishes when the sphere's centre is on the camera axis
         const bool axial = one && b->cc.q_uv == 0.0f;
         if(exact) {
@@ -1794,7 +1789,10 @@ int aehip_backend_stats(aehip_backend *b, aehip_stats *out) {
     float ms = 0.0f;
     AEHIP_CHECK(hipEventElapsedTime(&ms, b->ev_begin, b->ev_end));
     b->stats.kernel_ms = ms;
-    if(b->vc.flags & AEHIP_FLAG_COUNT_RAYS) {
+    if((b->vc.flags & AEHIP_FLAG_COUNT_RAYS) && b->counts_known) {
+        b->stats.rays = b->known_rays;
+        b->stats.lane_slots = b->known_lane_slots;
+    } else if(b->vc.flags & AEHIP_FLAG_COUNT_RAYS) {
         unsigned long long counters[2] = {0, 0};
         AEHIP_CHECK(hipMemcpy(counters, b->d_rays, sizeof(counters), hipMemcpyDeviceToHost));
         b->stats.rays = counters[0];
