@@ -694,13 +694,22 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
     }
 
     if(vc.flags & AEHIP_FLAG_COUNT_RAYS) {
-        // wave-level sum, one atomic per wave and counter
+        // wave-level sums, gathered per workgroup in LDS: one pair of global atomics per
+        // workgroup (every wave of a launch adding to the same two words serialises)
+        __shared__ uint32_t s_counts[2];
+        if(tid < 2) s_counts[tid] = 0;
+        __syncthreads();
         uint32_t v = nrays;
 #pragma unroll
         for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if((tid & 63u) == 0) {
-            atomicAdd(ray_counter, static_cast<unsigned long long>(v));
-            atomicAdd(ray_counter + 1, 64ull * iterations);
+            atomicAdd(&s_counts[0], v);
+            atomicAdd(&s_counts[1], iterations);
+        }
+        __syncthreads();
+        if(tid == 0) {
+            atomicAdd(ray_counter, static_cast<unsigned long long>(s_counts[0]));
+            atomicAdd(ray_counter + 1, 64ull * s_counts[1]);
         }
     }
 }
