@@ -525,17 +525,18 @@ __device__ __forceinline__ bool shade_segment(const view_consts &vc, uint32_t y,
     const f3 n = front ? n_out : f3{-n_out.x, -n_out.y, -n_out.z};
     f3 nd;
 
+    // the random unit vector of the diffuse and the fuzzy-metal branch, drawn once for both so a
+    // wave with lanes on either material runs the polynomial once
+    f3 u = {0.0f, 0.0f, 0.0f};
+    if(material == AEHIP_MAT_LAMBERT || (material == AEHIP_MAT_METAL && m.w > 0.0f)) u = unit_vector<EXACT>(rng_next(ps.rng));
+
     if(material == AEHIP_MAT_LAMBERT) {
-        const f3 u = unit_vector<EXACT>(rng_next(ps.rng));
         nd = f3{n.x + u.x, n.y + u.y, n.z + u.z};
         if(__builtin_fabsf(nd.x) < 1e-8f && __builtin_fabsf(nd.y) < 1e-8f && __builtin_fabsf(nd.z) < 1e-8f) nd = n;
     } else if(material == AEHIP_MAT_METAL) {
         const float k = 2.0f * dot3<EXACT>(ps.d, n);
         nd = f3{rt_fma<EXACT>(-k, n.x, ps.d.x), rt_fma<EXACT>(-k, n.y, ps.d.y), rt_fma<EXACT>(-k, n.z, ps.d.z)};
-        if(m.w > 0.0f) {
-            const f3 u = unit_vector<EXACT>(rng_next(ps.rng));
-            nd = f3{rt_fma<EXACT>(m.w, u.x, nd.x), rt_fma<EXACT>(m.w, u.y, nd.y), rt_fma<EXACT>(m.w, u.z, nd.z)};
-        }
+        if(m.w > 0.0f) nd = f3{rt_fma<EXACT>(m.w, u.x, nd.x), rt_fma<EXACT>(m.w, u.y, nd.y), rt_fma<EXACT>(m.w, u.z, nd.z)};
         if(!(dot3<EXACT>(nd, n) > 0.0f)) return true;      // absorbed
     } else {
         const float ri = front ? rt_div<EXACT>(1.0f, m.w) : m.w;
@@ -549,8 +550,8 @@ __device__ __forceinline__ bool shade_segment(const view_consts &vc, uint32_t y,
         const float w = 1.0f - cos_t;
         const float w2 = w * w;
         const float reflectance = rt_fma<EXACT>(1.0f - r0, (w2 * w2) * w, r0);
-        const float u = static_cast<float>(rng_next(ps.rng) >> 8) * (1.0f / 16777216.0f);
-        if(ri * sin_t > 1.0f || reflectance > u) {
+        const float draw = static_cast<float>(rng_next(ps.rng) >> 8) * (1.0f / 16777216.0f);
+        if(ri * sin_t > 1.0f || reflectance > draw) {
             const float k = 2.0f * dot3<EXACT>(ps.d, n);
             nd = f3{rt_fma<EXACT>(-k, n.x, ps.d.x), rt_fma<EXACT>(-k, n.y, ps.d.y), rt_fma<EXACT>(-k, n.z, ps.d.z)};
         } else {
