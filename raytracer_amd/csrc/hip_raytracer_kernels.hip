@@ -1702,17 +1702,22 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
             b->d_radiance = nullptr; b->d_totals = nullptr;
             b->radiance_capacity = 0; b->totals_capacity = 0;
         } else {
+            // a failed allocation is not an error: the per-lane pass needs no such buffer
             if(need > b->radiance_capacity) {
                 if(b->d_radiance) (void)hipFree(b->d_radiance);
                 b->d_radiance = nullptr; b->radiance_capacity = 0;
-                AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_radiance), need * sizeof(radiance3)));
-                b->radiance_capacity = need;
+                if(hipMalloc(reinterpret_cast<void **>(&b->d_radiance), need * sizeof(radiance3)) == hipSuccess) b->radiance_capacity = need;
+                else { b->d_radiance = nullptr; (void)hipGetLastError(); }
             }
-            if(pixels > b->totals_capacity) {
+            if(b->d_radiance && pixels > b->totals_capacity) {
                 if(b->d_totals) (void)hipFree(b->d_totals);
                 b->d_totals = nullptr; b->totals_capacity = 0;
-                AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_totals), pixels * sizeof(radiance3)));
-                b->totals_capacity = pixels;
+                if(hipMalloc(reinterpret_cast<void **>(&b->d_totals), pixels * sizeof(radiance3)) == hipSuccess) b->totals_capacity = pixels;
+                else {
+                    b->d_totals = nullptr; (void)hipGetLastError();
+                    (void)hipFree(b->d_radiance);
+                    b->d_radiance = nullptr; b->radiance_capacity = 0;
+                }
             }
         }
     }
