@@ -45,7 +45,8 @@ constexpr int kLdsSpheres = 2048;        // shape-list chunk staged in LDS: 2048
 constexpr int kPrimaryBlock = 256;       // primary pass: 256 threads x 4 pixels each
 constexpr float kTMin = 0.001f;
 constexpr uint32_t kFlagFoldScreen = 1u << 31;   // internal: screening rays may use folded per-pixel terms
-constexpr uint32_t kPoolMinSpheres = 16;  // shape lists at least this long use the streamed path pass (a 5-sphere scene: 2.1 ms per-lane, 6.5 ms streamed)
+constexpr uint32_t kPoolMinSpheres = 48;  // shape lists at least this long use the streamed path pass; measured crossover on the
+                                          // mixed-material scene (1080p, 16 spp): 32 spheres 1.35 ms per-lane / 1.77 streamed, 64: 2.26 / 1.85
 
 struct view_consts {
     float vw_half, vh_half;     // viewport_size * 0.5 (exact: power-of-two scale)

@@ -436,7 +436,7 @@ def test_tiled_bands_equal_the_whole_image(world, tile_rows, size):
     for fast in (False, True):
         whole_d, _ = rt.render(w, h, spp=8, max_depth=8, seed=3, jitter=True, fast=fast)
         np.testing.assert_array_equal(render_tiled(w, h, world, tile_rows, spp=8, max_depth=8, seed=3, jitter=True, fast=fast), whole_d)
-    # streamed pass (>= 16 spheres), both builds: per-path radiance summed in the specified order,
+    # streamed pass (>= 48 spheres), both builds: per-path radiance summed in the specified order,
     # independent of the order in which paths finish and so of the launch's shape
     many = scenes.divergence_scene()
     for fast in (True, False):
