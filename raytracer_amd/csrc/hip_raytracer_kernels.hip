@@ -45,8 +45,11 @@ constexpr int kLdsSpheres = 2048;        // shape-list chunk staged in LDS: 2048
 constexpr int kPrimaryBlock = 256;       // primary pass: 256 threads x 4 pixels each
 constexpr float kTMin = 0.001f;
 constexpr uint32_t kFlagFoldScreen = 1u << 31;   // internal: screening rays may use folded per-pixel terms
-constexpr uint32_t kPoolMinSpheres = 48;  // shape lists at least this long use the streamed path pass; measured crossover on the
-                                          // mixed-material scene (1080p, 16 spp): 32 spheres 1.35 ms per-lane / 1.77 streamed, 64: 2.26 / 1.85
+// Shape lists at least this long use the streamed path pass.  Which pass wins depends on path
+// lengths more than on the list: with long mixed-material paths the streamed pass is ahead from
+// 16 spheres (1080p 16 spp: 0.98 ms per-lane / 0.73 streamed; 64 spheres 2.30 / 1.90), with short
+// paths over 40 small spheres the per-lane pass is (0.45 / 0.73), as on a 5-sphere scene (1.9 / 2.6).
+constexpr uint32_t kPoolMinSpheres = 48;
 
 struct view_consts {
     float vw_half, vh_half;     // viewport_size * 0.5 (exact: power-of-two scale)
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
 //
 // A wave does not end with its unit: that would idle lanes while each pool drains (its last,
 // longest paths) and, per launch, while the last and heaviest waves finish on an emptying chip.
-// Units are numbered strip-major; a wave takes the next one from a global counter when its
+// A wave takes the next units from a global counter when its
 // current pool is dealt out, and deals the new unit's items to lanes as they come free while
 // other lanes are still finishing paths of earlier units.  A wave leaves when the queue is empty
 // and its own paths are done -- it never waits for another wave -- so lanes idle only in a
@@ -761,7 +764,7 @@ __global__ __launch_bounds__(kBlock) void path_stream_kernel(view_consts vc, con
                                                              const uint32_t *__restrict__ sample_terms,
                                                              radiance3 *__restrict__ radiance, uint32_t sample_begin,
                                                              uint32_t sample_count, unsigned long long *ray_counter,
-                                                             uint32_t *unit_queue) {
+                                                             uint32_t *unit_queue, uint32_t unit_batch) {
     constexpr int kWaves = kBlock / 64;
     __shared__ uint32_t s_term[kWaves][64];          // per-pixel key terms of the unit being dealt
 
@@ -770,11 +773,13 @@ __global__ __launch_bounds__(kBlock) void path_stream_kernel(view_consts vc, con
     const uint32_t strips_x = (vc.width + kTileW - 1) / kTileW;
     const uint32_t strips_y = (vc.row_count + 3u) / 4u;
     const uint32_t chunks = (sample_count + kChunkSamples - 1u) / kChunkSamples;     // units per strip
-    const uint32_t n_units = strips_x * strips_y * chunks;
+    const uint32_t n_strips = strips_x * strips_y;
+    const uint32_t n_units = n_strips * chunks;
 
     // wave-uniform state
     uint32_t pool = 0, cursor = 0;                   // items of the current unit, next undealt one (cursor == pool: none left)
     bool queue_empty = false;
+    uint32_t batch_next = 0, batch_end = 0;          // units taken from the queue and not yet started
     uint32_t strip = 0xffffffffu, strip_x0 = 0, strip_row0 = 0, chunk_begin = 0;      // no strip yet
 
     // lane state
@@ -791,14 +796,24 @@ __global__ __launch_bounds__(kBlock) void path_stream_kernel(view_consts vc, con
         const unsigned long long want = __ballot(!tracing);
         if(want != 0ull) {
             if(cursor >= pool && !queue_empty) {
-                uint32_t id = 0;
-                if(lane == 0) id = atomicAdd(unit_queue, 1u);
-                id = __builtin_amdgcn_readfirstlane(id);
-                if(id >= n_units) {
+                // Units are numbered chunk-major and taken kUnitBatch at a time: every wave of the
+                // launch adds to the same counter, and atomics on one address go through one at a
+                // time (130,000 single takes alone were 1.7 ms of a 1080p 16-spp launch).  The
+                // units of a batch are neighbouring strips at the same samples, so a heavy strip's
+                // chunks still go to different waves.
+                if(batch_next >= batch_end) {
+                    uint32_t first = 0;
+                    if(lane == 0) first = atomicAdd(unit_queue, unit_batch);
+                    batch_next = __builtin_amdgcn_readfirstlane(first);
+                    batch_end = min(batch_next + unit_batch, n_units);
+                }
+                if(batch_next >= n_units) {
                     queue_empty = true;
                 } else {
-                    const uint32_t new_strip = id / chunks;
-                    chunk_begin = (id - new_strip * chunks) * kChunkSamples;
+                    const uint32_t id = batch_next++;
+                    const uint32_t chunk = id / n_strips;
+                    const uint32_t new_strip = id - chunk * n_strips;
+                    chunk_begin = chunk * kChunkSamples;
                     pool = 64u * min(kChunkSamples, sample_count - chunk_begin);
                     cursor = 0;
                     if(new_strip != strip) {
@@ -1429,6 +1444,11 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
             const uint32_t resident = static_cast<uint32_t>(per_cu > 0 ? per_cu : 1) * static_cast<uint32_t>(b->cu_count);
             const uint32_t nblocks = (vc.spp + AEHIP_SAMPLE_BLOCK - 1u) / AEHIP_SAMPLE_BLOCK;
             func = exact ? reinterpret_cast<const void *>(path_stream_kernel<true>) : reinterpret_cast<const void *>(path_stream_kernel<false>);
+            // Units a wave takes per atomic.  Every wave of the launch adds to the same counter and
+            // atomics on one address go through one at a time (13 ns each measured: 130,000 single
+            // takes are 1.7 ms of a 1080p 16-spp launch), so cheap units are taken several at a
+            // time; costly ones singly, for the finest balance at the end of the launch.
+            const uint32_t unit_batch = std::min(16u, std::max(1u, 128u / vc.n_spheres));
             for(uint32_t blk = 0; blk < nblocks; blk++) {
                 const uint32_t begin = blk * AEHIP_SAMPLE_BLOCK;
                 const uint32_t count = std::min(AEHIP_SAMPLE_BLOCK, vc.spp - begin);
@@ -1437,10 +1457,10 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
                 AEHIP_CHECK(hipMemsetAsync(b->d_rays + 2, 0, sizeof(unsigned long long), stream));
                 if(exact)
                     hipLaunchKernelGGL(path_stream_kernel<true>, dim3(groups), dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind,
-                                       b->d_sample_terms, b->d_radiance, begin, count, b->d_rays, reinterpret_cast<uint32_t *>(b->d_rays + 2));
+                                       b->d_sample_terms, b->d_radiance, begin, count, b->d_rays, reinterpret_cast<uint32_t *>(b->d_rays + 2), unit_batch);
                 else
                     hipLaunchKernelGGL(path_stream_kernel<false>, dim3(groups), dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind,
-                                       b->d_sample_terms, b->d_radiance, begin, count, b->d_rays, reinterpret_cast<uint32_t *>(b->d_rays + 2));
+                                       b->d_sample_terms, b->d_radiance, begin, count, b->d_rays, reinterpret_cast<uint32_t *>(b->d_rays + 2), unit_batch);
                 hipLaunchKernelGGL(resolve_block_kernel, dim3((strips + 3u) / 4u), dim3(kBlock), 0, stream, vc, b->d_radiance, b->d_totals,
                                    count, blk == 0 ? 1u : 0u, blk + 1 == nblocks ? 1u : 0u, argb_dev, rgba);
             }
