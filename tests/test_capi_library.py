@@ -35,6 +35,31 @@ def test_struct_layouts_match_header():
     assert raytracer_amd.SPHERE_DTYPE.itemsize == 48
 
 
+def test_field_offsets_match_the_compiled_header(tmp_path):
+    """The header itself, compiled as C, against the ctypes mirrors: size and offset of every field."""
+    import subprocess
+
+    structs = {"aehip_params": raytracer_amd.AehipParams, "aehip_scene": raytracer_amd.AehipScene,
+               "aehip_stats": raytracer_amd.AehipStats}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hip_raytracer.h"', "int main(void) {"]
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, *_ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname.rstrip("_")}));')     # pass_ mirrors `pass`
+    lines += ['  printf("aehip_sphere size %zu\\n", sizeof(aehip_sphere));', "  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.dirname(HEADER), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out if l}
+    for cname, cls in structs.items():
+        assert got[(cname, "size")] == ctypes.sizeof(cls)
+        for fname, *_ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+    assert got[("aehip_sphere", "size")] == raytracer_amd.SPHERE_DTYPE.itemsize
+
+
 def test_null_arguments_are_rejected_without_touching_a_device():
     lib = raytracer_amd.load()
     assert lib.aehip_backend_create(0, None, None) == -2
