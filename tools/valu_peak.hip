@@ -54,6 +54,11 @@ __global__ __launch_bounds__(256) void probe(float *out, float seed, unsigned us
             if constexpr(KIND == 11) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(u[i]));
             if constexpr(KIND == 12) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(u[i]));
             if constexpr(KIND == 13) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(u[i]) : "v"(um));
+            if constexpr(KIND == 16) asm volatile("v_cvt_f32_u32_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "+v"(u[i]));
+            if constexpr(KIND == 17) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(u[i]));
+            if constexpr(KIND == 18) asm volatile("v_alignbit_b32 %0, %1, %0, 9" : "+v"(u[i]) : "v"(um));
+            if constexpr(KIND == 19) asm volatile("v_cmp_le_f32 vcc, 0, %0" : : "v"(a[i]) : "vcc");
+            if constexpr(KIND == 20) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(um));
             if constexpr(KIND == 14) a[i] = m / a[i];                    // IEEE-correct division
             if constexpr(KIND == 15) a[i] = __builtin_sqrtf(a[i] + m);   // IEEE-correct sqrt (+1 add)
         }
@@ -109,6 +114,11 @@ int main() {
     run<11>("lshr", 0, d_out);
     run<12>("cvt_f32_u32", 0, d_out);
     run<13>("mad_u32_u24", 0, d_out);
+    run<16>("cvt_sdwa_w1", 0, d_out);
+    run<17>("cvt_ubyte1", 0, d_out);
+    run<18>("alignbit", 0, d_out);
+    run<19>("cmp_f32", 0, d_out);
+    run<20>("add_u32", 0, d_out);
     run<14>("div_ieee", 1, d_out);
     run<15>("sqrt_ieee", 1, d_out);
     HIPCHK(hipFree(d_out));
