@@ -5,7 +5,7 @@
 // single sphere is generalised to a list that --scene can replace.
 #pragma once
 
-#include "common.h"
+#include "host_types.h"
 #include "hip_raytracer.h"
 
 #include <utility>

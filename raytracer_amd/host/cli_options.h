@@ -8,7 +8,7 @@
 // reference's behaviour (1 sample at the pixel centre, depth 1, built-in scene).
 #pragma once
 
-#include "common.h"
+#include "host_types.h"
 
 #include <map>
 #include <span>

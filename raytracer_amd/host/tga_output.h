@@ -8,7 +8,7 @@
 // compares equal byte for byte; `tight` selects 18 + w*h*4 instead.
 #pragma once
 
-#include "common.h"
+#include "host_types.h"
 
 #include <string>
 
