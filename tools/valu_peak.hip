@@ -59,6 +59,11 @@ __global__ __launch_bounds__(256) void probe(float *out, float seed, unsigned us
             if constexpr(KIND == 18) asm volatile("v_alignbit_b32 %0, %1, %0, 9" : "+v"(u[i]) : "v"(um));
             if constexpr(KIND == 19) asm volatile("v_cmp_le_f32 vcc, 0, %0" : : "v"(a[i]) : "vcc");
             if constexpr(KIND == 20) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(um));
+            if constexpr(KIND == 21) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(u[i]) : "v"(um), "v"(um));
+            if constexpr(KIND == 22) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(u[i]) : "v"(um));
+            if constexpr(KIND == 23) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(u[i]) : "v"(um));
+            if constexpr(KIND == 24) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(u[i]) : "v"(a[i]), "v"(m));
+            if constexpr(KIND == 25) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(u[i]) : "v"(um));
             if constexpr(KIND == 14) a[i] = m / a[i];                    // IEEE-correct division
             if constexpr(KIND == 15) a[i] = __builtin_sqrtf(a[i] + m);   // IEEE-correct sqrt (+1 add)
         }
@@ -119,6 +124,11 @@ int main() {
     run<18>("alignbit", 0, d_out);
     run<19>("cmp_f32", 0, d_out);
     run<20>("add_u32", 0, d_out);
+    run<21>("pk_fma_f16", 4, d_out);
+    run<22>("pk_add_f16", 2, d_out);
+    run<23>("pk_mul_f16", 2, d_out);
+    run<24>("cvt_pkrtz", 0, d_out);
+    run<25>("pk_max_f16", 0, d_out);
     run<14>("div_ieee", 1, d_out);
     run<15>("sqrt_ieee", 1, d_out);
     HIPCHK(hipFree(d_out));
