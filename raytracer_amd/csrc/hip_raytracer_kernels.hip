@@ -412,7 +412,10 @@ template <bool EXACT>
 __device__ __forceinline__ void resolve_sphere(const float4 g, int index, float screen, float h, const f3 o, const f3 d,
                                                float a2, float a4, float &closest, int &hit) {
     if(!(screen >= 0.0f)) return;
-    float t_near, t_far;
+    // near root if it lies in (t_min, closest), else the far root if it does.  A near root at or
+    // beyond `closest` leaves nothing for the far one (t_far >= t_near), so one range test serves,
+    // and the far root is only worked out when the near one is behind t_min.
+    float t;
     if constexpr(EXACT) {
         const f3 oc = {g.x - o.x, g.y - o.y, g.z - o.z};
         const float b = -2.0f * dot3<true>(d, oc);
@@ -420,16 +423,13 @@ __device__ __forceinline__ void resolve_sphere(const float4 g, int index, float 
         const float disc = b * b - a4 * c;
         if(!(disc >= 0.0f)) return;
         const float sq = rt_sqrt<true>(disc);
-        t_near = (-b - sq) / a2;
-        t_far = (-b + sq) / a2;
+        t = (-b - sq) / a2;
+        if(!(t > kTMin)) t = (-b + sq) / a2;
     } else {
         const float sq = __builtin_amdgcn_sqrtf(screen);
-        t_near = h - sq;
-        t_far = h + sq;
+        t = h - sq;
+        if(!(t > kTMin)) t = h + sq;
     }
-    // near root if it lies in (t_min, closest), else the far root if it does.  A near root at or
-    // beyond `closest` leaves nothing for the far one (t_far >= t_near), so one range test serves.
-    const float t = t_near > kTMin ? t_near : t_far;
     if((t > kTMin) && (t < closest)) {
         closest = t;
         hit = index;
