@@ -417,6 +417,16 @@ __device__ __forceinline__ void resolve_sphere(const float4 g, int index, float 
     // and the far root is only worked out when the near one is behind t_min.
     float t;
     if constexpr(EXACT) {
+        // Cheap bounds on both roots before the exact arithmetic.  `screen` is at least a quarter
+        // of the exact discriminant (that is what its margin is for) and h is d.oc to rounding, so
+        // the exact roots lie in [h - s - slack, h + s + slack] with s = sqrt(screen); the slack
+        // (1e-5 of the magnitudes involved, the radius bounded by 1 + r*r) is ten times what the
+        // roundings of h, of the square root and of the division by 2a can add up to.  A sphere
+        // whose nearest possible root is not nearer than the current hit, or whose farthest is
+        // behind t_min, cannot change the result: most spheres a ray's line passes through.
+        const float s = __builtin_amdgcn_sqrtf(screen);
+        const float slack = 1e-5f * (__builtin_fabsf(h) + s + 1.0f + g.w);
+        if(h - s - slack >= closest || h + s + slack <= kTMin) return;
         const f3 oc = {g.x - o.x, g.y - o.y, g.z - o.z};
         const float b = -2.0f * dot3<true>(d, oc);
         const float c = dot3<true>(oc, oc) - g.w;
