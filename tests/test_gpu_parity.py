@@ -445,6 +445,22 @@ def test_tiled_bands_equal_the_whole_image(world, tile_rows, size):
         np.testing.assert_array_equal(tiled_s, whole_s)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_random_band_splits_equal_the_whole_image(seed):
+    """Random image sizes, rank counts, tile heights, scenes and builds: the bands, put back in image
+    order, are the image one launch renders -- whichever kernel serves the scene."""
+    rng = np.random.default_rng(9000 + seed)
+    w, h = int(rng.integers(17, 140)), int(rng.integers(9, 90))
+    tile_rows = int(rng.choice([1, 2, 3, 4, 5, 8, 16]))
+    world = int(rng.integers(2, 6))
+    world = min(world, -(-h // tile_rows))
+    spheres = [None, scenes.showcase_scene(), scenes.divergence_scene(), scenes.stress_scene(60, seed)][seed % 4]
+    kw = dict(spp=int(rng.choice([1, 3, 9, 66])), max_depth=int(rng.choice([1, 3, 9])), seed=seed, jitter=bool(seed % 2),
+              fast=bool((seed // 4) % 2), spheres=spheres)
+    whole, _ = rt.render(w, h, **kw)
+    np.testing.assert_array_equal(render_tiled(w, h, world, tile_rows, **kw), whole)
+
+
 def test_setup_rejects_bad_tile_requests():
     back = rt.HipRaytracer(None)
     try:
