@@ -602,3 +602,27 @@ def test_config_4k_jitter_free_sub_case_is_the_reference_image_through_the_sampl
     parts = [rt.render(w, h, spp=1, max_depth=8, pass_=rt.PASS_PATH, row_begin=bounds[g], row_count=bounds[g + 1] - bounds[g])[0]
              for g in range(gpus)]
     assert sha(np.concatenate(parts, axis=0)) == want
+
+
+# ------------------------------------------------------------------ host-buffer call in parts
+
+@pytest.mark.parametrize("case", [
+    dict(width=1400, height=1000, spp=3, max_depth=1, jitter=True),
+    dict(width=1400, height=1000, spp=3, max_depth=1, jitter=True, fast=True),
+    dict(width=2048, height=515, spp=1, max_depth=1, pass_=rt.PASS_PRIMARY),
+    dict(width=1920, height=1080, spp=2, max_depth=6, jitter=True, fast=True, scene="divergence"),
+    dict(width=1536, height=2000, spp=2, max_depth=1, jitter=True, row_begin=301, row_count=1211),
+], ids=["exact", "fast", "primary", "streamed", "band"])
+def test_host_buffer_call_in_parts_equals_the_single_launch(case):
+    """aehip_backend_trace renders a band of a megapixel or more in several launches so that the
+    copies to the host overlap the rendering; the image must be the one a single launch into
+    device memory gives, and the path count the whole band's."""
+    kw = dict(case)
+    scene = kw.pop("scene", None)
+    if scene:
+        kw["spheres"] = scenes.divergence_scene()
+    w, h = kw.pop("width"), kw.pop("height")
+    host, st = rt.render(w, h, **kw)
+    dev, _, st_dev = render_device(w, h, want_rgba=False, **kw)
+    np.testing.assert_array_equal(host, dev)
+    assert st.paths == st_dev.paths
