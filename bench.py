@@ -159,14 +159,20 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
-    # everything runs on one side stream: the library treats the null stream as "use your own and
-    # wait", and launches are to queue back to back without the host in between
+    # everything runs on side streams: the library treats the null stream as "use your own and
+    # wait", and launches are to queue back to back without the host in between.  With several
+    # ranks a frame is a fraction of a millisecond and its ramp and tail weigh: consecutive frames
+    # go to two streams in turn, so frame i+1 fills the compute units that frame i's last
+    # workgroups leave idle (an eighth of the 4K frame: 0.259 -> 0.240 ms fast, 1.05 -> 0.90 ms
+    # exact, tools/frame_overlap.py).  One rank keeps one stream, so that a launch's duration
+    # means the same here and in the profiler's kernel trace.
     if share:
-        stream = None                   # gloo's device-tensor path is slow off the default stream
+        sides = None                    # gloo's device-tensor path is slow off the default stream
+        stream = None
     else:
-        side = torch.cuda.Stream(device=device)
-        torch.cuda.set_stream(side)
-        stream = side.cuda_stream
+        sides = [torch.cuda.Stream(device=device) for _ in range(2 if world > 1 else 1)]
+        torch.cuda.set_stream(sides[0])
+        stream = sides[0].cuda_stream
     gather = BandGather(WIDTH, HEIGHT, device)
     overlap = not share                 # gloo's asynchronous gather of device tensors does not complete here
 
@@ -188,20 +194,30 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
+            if sides is not None:
+                torch.cuda.set_stream(sides[i % len(sides)])
+            on = torch.cuda.current_stream().cuda_stream if sides is not None else None
             band = gather.begin(i) if overlap else gather.local
             ev[i][0].record()                   # alternating band buffers: the gather of frame i
-            back.trace_device(band.data_ptr(), None, stream)    # overlaps the render of frame i+1
+            back.trace_device(band.data_ptr(), None, on)        # overlaps the render of frame i+1
             ev[i][1].record()
             if overlap:
                 gather.submit(i)
             else:
                 gather.gather()
+        if sides is not None:
+            torch.cuda.set_stream(sides[0])
         gather.finish()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+        if sides is not None and len(sides) > 1:
+            # launches overlap: a launch's own span counts the time it shared the GPU, so take the
+            # frames' common span per frame instead
+            kernel_ms = ev[0][0].elapsed_time(ev[-1][1]) / steps
+        else:
+            kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
         t = torch.tensor([elapsed, kernel_ms * 1e-3], dtype=torch.float64, device=device)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -60,13 +60,24 @@ class BandGather:
     buffer to render frame i into, `submit(i)` starts its gather without waiting, `finish()`
     waits for everything submitted.  `gather()` is the simple blocking form on buffer 0.
 
-    `band` holds the aehip_params fields of this rank's band (pass as **band to setup())."""
+    On a GPU every call orders its work on the stream that is current when it is made, and
+    begin()/submit() of consecutive frames may be made on two different streams (frame i on
+    stream i & 1): frame i+1 then starts while the last workgroups of frame i drain, which is
+    worth 2 % of a whole 4K frame and 8-15 % of an eighth of one.  A buffer is handed out again
+    only after the gather that read it, wherever that gather was waited for.
 
-    def __init__(self, width: int, height: int, device: torch.device, dst: int = 0, tile_rows: int = 4):
+    `band` holds the aehip_params fields of this rank's band (pass as **band to setup()).
+    `always_collective` runs the collective and the stacked-bands path even for a single rank
+    (tests of the protocol on one GPU)."""
+
+    def __init__(self, width: int, height: int, device: torch.device, dst: int = 0, tile_rows: int = 4,
+                 always_collective: bool = False):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.dst = dst
         self.width, self.height = width, height
+        self.on_gpu = torch.device(device).type == "cuda"
+        self.collective = self.world > 1 or always_collective
         self.bands = [tiled_band(height, self.world, r, tile_rows) for r in range(self.world)]
         self.band = self.bands[self.rank]
         self.row_begin, self.rows = self.band["row_begin"], self.band["row_count"]
@@ -81,7 +92,7 @@ class BandGather:
         self._row_source = None
         if self.rank == dst:
             self.image = torch.zeros((height, width), dtype=torch.int32, device=device)
-            if self.even and not self.tiled:
+            if self.even and not self.tiled and not always_collective:
                 # equal contiguous bands: receive straight into the rows of the final image
                 self.parts = [self.image[b["row_begin"]:b["row_begin"] + b["row_count"]] for b in self.bands]
             else:
@@ -94,6 +105,11 @@ class BandGather:
                     src[torch.tensor(rows, dtype=torch.int64)] = torch.arange(len(rows), dtype=torch.int64) + r * self.max_rows
                 self._row_source = src.to(device)
         self._pending = [None, None]
+        # per buffer: event after which the buffer may be rendered into again; single rank: event of
+        # the last copy into the image (an event is re-recorded freely: a wait holds the record it saw)
+        self._events = [torch.cuda.Event() for _ in range(3)] if self.on_gpu else None
+        self._free = [None, None]
+        self._copied = None
 
     # ------------------------------------------------------------------ blocking form
 
@@ -108,6 +124,8 @@ class BandGather:
         """Buffer to render `frame` into.  Waits (stream-side) for the gather that last read it."""
         slot = frame & 1
         self._complete(slot)
+        if self._free[slot] is not None:
+            torch.cuda.current_stream().wait_event(self._free[slot])
         return self.locals[slot]
 
     def submit(self, frame: int) -> None:
@@ -131,17 +149,26 @@ class BandGather:
             self._pending[slot].wait()
             self._pending[slot] = None
             self._assemble()
+            if self.on_gpu:
+                # the stream this ran on may not be the one that renders into the buffer next
+                self._free[slot] = self._events[slot]
+                self._free[slot].record()
 
     def _start(self, slot: int, async_op: bool):
         src = self.locals[slot]
-        if self.world == 1:
+        if not self.collective:
+            if self.on_gpu and self._copied is not None:
+                torch.cuda.current_stream().wait_event(self._copied)     # frames reach the image in order
             self.image[: self.rows].copy_(src[: self.rows])
+            if self.on_gpu:
+                self._copied = self._events[2]
+                self._copied.record()
             return None
         return dist.gather(src, self.parts if self.rank == self.dst else None, dst=self.dst, async_op=async_op)
 
     def _assemble(self) -> torch.Tensor | None:
         if self.rank != self.dst:
             return None
-        if self._row_source is not None and self.world > 1:
+        if self._row_source is not None and self.collective:
             torch.index_select(self._recv.view(self.world * self.max_rows, self.width), 0, self._row_source, out=self.image)
         return self.image
