@@ -358,24 +358,29 @@ def aux_measurements(rt, torch, stream):
                      "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": nbytes,
                      "note": "33 MB store per launch; launches back to back, so the figure includes launch gaps"},
     }
-    # brute-force list (config "~10k random spheres"): every ray tests every sphere, 18 flop per test;
-    # primary rays only so that every lane is busy and the figure is the intersection loop's own
+    # brute-force list (config "~10k random spheres"): every ray tests every sphere, 18 flop per test
+    # as the reference writes it.  Depth 1: camera rays only, every lane busy; the kernel walks the
+    # table of per-sphere camera constants (4 operations a test).  Depth 4: the streamed pass, rays
+    # from anywhere (10 operations a test), shading and lane utilisation included.
     sph = scenes.stress_scene(10000, 42)
     for mode in ("fast", "exact"):
-        back = rt.HipRaytracer(None)
-        flags = rt.FLAG_JITTER | rt.FLAG_COUNT_RAYS | (rt.FLAG_FAST if mode == "fast" else 0)
-        back.setup(1920, 1080, spp=2, max_depth=1, seed=1, flags=flags, pass_=rt.PASS_PATH, spheres=sph)
-        img = torch.zeros((1080, 1920), dtype=torch.int32, device="cuda")
-        best, s = settled_kernel_ms(back, img, torch, stream)
-        tests = s.rays * len(sph)
-        tf = tests * 18.0 / (best * 1e-3) / 1e12
-        out[f"stress10k_1080p_2spp_depth1_{mode}"] = {
-            "kernel_ms": best, "sphere_tests_per_s": tests / (best * 1e-3), "mpaths_per_s": s.paths / best / 1e3,
-            "rays_per_s": s.rays / (best * 1e-3),
-            "roofline": {"bound": "valu_fp32", "achieved": tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf / FP32_VECTOR_PEAK_TFLOPS, "kernel": "path_kernel (scalar-cache list stream)"},
-        }
-        back.close()
+        for spp, depth, kernel in ((2, 1, "path_kernel (camera table through the scalar cache)"),
+                                   (4, 4, "path_stream_kernel (sphere list through the scalar cache)")):
+            back = rt.HipRaytracer(None)
+            flags = rt.FLAG_JITTER | rt.FLAG_COUNT_RAYS | (rt.FLAG_FAST if mode == "fast" else 0)
+            back.setup(1920, 1080, spp=spp, max_depth=depth, seed=1, flags=flags, pass_=rt.PASS_PATH, spheres=sph)
+            img = torch.zeros((1080, 1920), dtype=torch.int32, device="cuda")
+            best, s = settled_kernel_ms(back, img, torch, stream, launches=4 if depth == 1 else 2)
+            tests = s.rays * len(sph)
+            tf = tests * 18.0 / (best * 1e-3) / 1e12
+            out[f"stress10k_1080p_{spp}spp_depth{depth}_{mode}"] = {
+                "kernel_ms": best, "sphere_tests_per_s": tests / (best * 1e-3), "mpaths_per_s": s.paths / best / 1e3,
+                "rays_per_s": s.rays / (best * 1e-3), "rays_per_path": s.rays / s.paths,
+                "lane_utilisation": s.rays / s.lane_slots,
+                "roofline": {"bound": "valu_fp32", "achieved": tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": tf / FP32_VECTOR_PEAK_TFLOPS, "kernel": kernel},
+            }
+            back.close()
     # divergence-heavy scene (mixed diffuse / metal / dielectric, depth 50): lane utilisation of the
     # bounce loop with and without path regeneration
     sph = scenes.divergence_scene(300, 7)

@@ -450,6 +450,19 @@ __device__ __forceinline__ void resolve_sphere(const float4 g, int index, float 
     }
 }
 
+// Rays that start at the camera (the first segment of every path) meet per-sphere constants:
+// oc = C - camera and the part of the screening value that does not depend on the direction
+// (-c, with the exact build's margin folded in).  Set-up tabulates them as (oc.xyz, u); the
+// screening value is then h*h + u with h = d.oc: 4 operations a sphere instead of 10.  h and,
+// in the fast build, the value have the same bits as screen_sphere's (same operations in the same
+// order, on the host for the tabulated part); the exact build's u is rounded once more, far
+// inside the margin.  Spheres that pass are resolved from the sphere list as ever.
+__device__ __forceinline__ float screen_camera_entry(const float4 e, const f3 d, float &h_out) {
+    const float h = __builtin_fmaf(d.z, e.z, __builtin_fmaf(d.y, e.y, d.x * e.x));
+    h_out = h;
+    return __builtin_fmaf(h, h, e.w);
+}
+
 struct sphere_group {
     float4 g0, g1, g2, g3;
 };
@@ -459,50 +472,66 @@ __device__ __forceinline__ sphere_group load_group(const float4 *__restrict__ li
     return sphere_group{p[0], p[1], p[2], p[3]};
 }
 
-template <bool EXACT>
-__device__ __forceinline__ void test_group(const sphere_group &sg, int index, const f3 o, const f3 d, float a2, float a4,
-                                           float &closest, int &hit) {
+// CAMERA: `sg` holds camera entries and `spheres` is the sphere list they were tabulated from.
+template <bool EXACT, bool CAMERA>
+__device__ __forceinline__ void test_group(const sphere_group &sg, const float4 *__restrict__ spheres, int index, const f3 o,
+                                           const f3 d, float a2, float a4, float &closest, int &hit) {
     float h0, h1, h2, h3;
-    const float k0 = screen_sphere<EXACT>(sg.g0, o, d, h0);
-    const float k1 = screen_sphere<EXACT>(sg.g1, o, d, h1);
-    const float k2 = screen_sphere<EXACT>(sg.g2, o, d, h2);
-    const float k3 = screen_sphere<EXACT>(sg.g3, o, d, h3);
+    const float k0 = CAMERA ? screen_camera_entry(sg.g0, d, h0) : screen_sphere<EXACT>(sg.g0, o, d, h0);
+    const float k1 = CAMERA ? screen_camera_entry(sg.g1, d, h1) : screen_sphere<EXACT>(sg.g1, o, d, h1);
+    const float k2 = CAMERA ? screen_camera_entry(sg.g2, d, h2) : screen_sphere<EXACT>(sg.g2, o, d, h2);
+    const float k3 = CAMERA ? screen_camera_entry(sg.g3, d, h3) : screen_sphere<EXACT>(sg.g3, o, d, h3);
     if(__builtin_fmaxf(__builtin_fmaxf(k0, k1), __builtin_fmaxf(k2, k3)) >= 0.0f) {
-        resolve_sphere<EXACT>(sg.g0, index, k0, h0, o, d, a2, a4, closest, hit);
-        resolve_sphere<EXACT>(sg.g1, index + 1, k1, h1, o, d, a2, a4, closest, hit);
-        resolve_sphere<EXACT>(sg.g2, index + 2, k2, h2, o, d, a2, a4, closest, hit);
-        resolve_sphere<EXACT>(sg.g3, index + 3, k3, h3, o, d, a2, a4, closest, hit);
+        if constexpr(CAMERA) {
+            // the spheres themselves are only fetched for the few that pass (exact build; the fast
+            // build's roots come from the screening value and h alone)
+            if(k0 >= 0.0f) resolve_sphere<EXACT>(spheres[index], index, k0, h0, o, d, a2, a4, closest, hit);
+            if(k1 >= 0.0f) resolve_sphere<EXACT>(spheres[index + 1], index + 1, k1, h1, o, d, a2, a4, closest, hit);
+            if(k2 >= 0.0f) resolve_sphere<EXACT>(spheres[index + 2], index + 2, k2, h2, o, d, a2, a4, closest, hit);
+            if(k3 >= 0.0f) resolve_sphere<EXACT>(spheres[index + 3], index + 3, k3, h3, o, d, a2, a4, closest, hit);
+        } else {
+            resolve_sphere<EXACT>(sg.g0, index, k0, h0, o, d, a2, a4, closest, hit);
+            resolve_sphere<EXACT>(sg.g1, index + 1, k1, h1, o, d, a2, a4, closest, hit);
+            resolve_sphere<EXACT>(sg.g2, index + 2, k2, h2, o, d, a2, a4, closest, hit);
+            resolve_sphere<EXACT>(sg.g3, index + 3, k3, h3, o, d, a2, a4, closest, hit);
+        }
     }
 }
 
 // `list` is either the LDS chunk or (scalar mode) the list in global memory read with a
 // wave-uniform index.  Groups are fetched one ahead of the group being tested, alternating two
 // register sets so no copies are needed: the fetch of group g+1 is in flight while group g is
-// screened.
-template <bool EXACT>
+// screened.  CAMERA: `list` is the table of camera entries and `spheres` the sphere list.
+template <bool EXACT, bool CAMERA = false>
 __device__ __forceinline__ void intersect_chunk(const float4 *__restrict__ list, uint32_t count, uint32_t index_base,
-                                                const f3 o, const f3 d, float a2, float a4, float &closest, int &hit) {
+                                                const f3 o, const f3 d, float a2, float a4, float &closest, int &hit,
+                                                const float4 *__restrict__ spheres = nullptr) {
     const uint32_t groups = count / 4u;
     uint32_t g = 0;
     if(groups > 0) {
         sphere_group A = load_group(list, 0);
         while(g + 2 <= groups) {
             const sphere_group B = load_group(list, g + 1);
-            test_group<EXACT>(A, static_cast<int>(index_base + g * 4u), o, d, a2, a4, closest, hit);
+            test_group<EXACT, CAMERA>(A, spheres, static_cast<int>(index_base + g * 4u), o, d, a2, a4, closest, hit);
             A = load_group(list, min(g + 2, groups - 1));      // clamped: the last fetch may repeat a group
-            test_group<EXACT>(B, static_cast<int>(index_base + (g + 1) * 4u), o, d, a2, a4, closest, hit);
+            test_group<EXACT, CAMERA>(B, spheres, static_cast<int>(index_base + (g + 1) * 4u), o, d, a2, a4, closest, hit);
             g += 2;
         }
         if(g < groups) {
-            test_group<EXACT>(A, static_cast<int>(index_base + g * 4u), o, d, a2, a4, closest, hit);
+            test_group<EXACT, CAMERA>(A, spheres, static_cast<int>(index_base + g * 4u), o, d, a2, a4, closest, hit);
             g++;
         }
     }
     for(uint32_t i = g * 4u; i < count; i++) {
         const float4 s = list[i];
         float h;
-        const float k = screen_sphere<EXACT>(s, o, d, h);
-        resolve_sphere<EXACT>(s, static_cast<int>(index_base + i), k, h, o, d, a2, a4, closest, hit);
+        if constexpr(CAMERA) {
+            const float k = screen_camera_entry(s, d, h);
+            if(k >= 0.0f) resolve_sphere<EXACT>(spheres[index_base + i], static_cast<int>(index_base + i), k, h, o, d, a2, a4, closest, hit);
+        } else {
+            const float k = screen_sphere<EXACT>(s, o, d, h);
+            resolve_sphere<EXACT>(s, static_cast<int>(index_base + i), k, h, o, d, a2, a4, closest, hit);
+        }
     }
 }
 
@@ -608,7 +637,8 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
                                                       const float4 *__restrict__ matl,
                                                       const uint32_t *__restrict__ kind,
                                                       const uint32_t *__restrict__ sample_terms, uint32_t *__restrict__ argb,
-                                                      float4 *__restrict__ rgba, unsigned long long *ray_counter) {
+                                                      float4 *__restrict__ rgba, unsigned long long *ray_counter,
+                                                      const float4 *__restrict__ camera_list) {
     constexpr bool SINGLE_CHUNK = LIST != kListLdsChunked;      // no workgroup barrier in the loop
     __shared__ float4 s_geom[LIST == kListScalar ? 1 : kLdsSpheres];
 
@@ -663,7 +693,13 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
         if constexpr(LIST == kListLdsOnce) {
             if(tracing) intersect_chunk<EXACT>(s_geom, vc.n_spheres, 0, ps.o, ps.d, a2, a4, closest, hit);
         } else if constexpr(LIST == kListScalar) {
-            if(tracing) intersect_chunk<EXACT>(geom, vc.n_spheres, 0, ps.o, ps.d, a2, a4, closest, hit);
+            // a wave whose rays all start at the camera (every wave of a one-segment render, the
+            // first iteration otherwise) walks the table of camera entries instead
+            if(!__any(tracing && ps.bounce != 0)) {
+                if(tracing) intersect_chunk<EXACT, true>(camera_list, vc.n_spheres, 0, ps.o, ps.d, a2, a4, closest, hit, geom);
+            } else {
+                if(tracing) intersect_chunk<EXACT>(geom, vc.n_spheres, 0, ps.o, ps.d, a2, a4, closest, hit);
+            }
         } else {
             for(uint32_t base = 0; base < vc.n_spheres; base += kLdsSpheres) {
                 const uint32_t count = min(static_cast<uint32_t>(kLdsSpheres), vc.n_spheres - base);
@@ -1347,6 +1383,7 @@ struct aehip_backend {
     camera_consts cc{};                      // sphere 0 relative to the camera (camera_kernel, ONE)
 
     float4 *d_geom = nullptr;                // n x (cx, cy, cz, r*r)
+    float4 *d_camera = nullptr;              // n x (oc.xyz, u): camera entries, see screen_camera_entry
     float4 *d_matl = nullptr;                // n x (albedo rgb, param)
     uint32_t *d_kind = nullptr;              // n x material id
     uint32_t scene_capacity = 0;
@@ -1455,7 +1492,7 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
     do {                                                                                                               \
         func = reinterpret_cast<const void *>(path_kernel<E, L>);                                                      \
         hipLaunchKernelGGL((path_kernel<E, L>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind,    \
-                           b->d_sample_terms, argb_dev, rgba, b->d_rays);                                              \
+                           b->d_sample_terms, argb_dev, rgba, b->d_rays, b->d_camera);                                 \
     } while(0)
         if(takes_streamed_pass(b)) {
             // persistent waves: no more workgroups than the chip holds at once (a larger grid
@@ -1685,8 +1722,10 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
         if(b->d_geom) (void)hipFree(b->d_geom);
         if(b->d_matl) (void)hipFree(b->d_matl);
         if(b->d_kind) (void)hipFree(b->d_kind);
-        b->d_geom = nullptr; b->d_matl = nullptr; b->d_kind = nullptr; b->scene_capacity = 0;
+        if(b->d_camera) (void)hipFree(b->d_camera);
+        b->d_geom = nullptr; b->d_matl = nullptr; b->d_kind = nullptr; b->d_camera = nullptr; b->scene_capacity = 0;
         AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_geom), sizeof(float4) * n));
+        AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_camera), sizeof(float4) * n));
         AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_matl), sizeof(float4) * n));
         AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_kind), sizeof(uint32_t) * n));
         b->scene_capacity = n;
@@ -1695,8 +1734,9 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
         float4 *geom = static_cast<float4 *>(std::malloc(sizeof(float4) * n));
         float4 *matl = static_cast<float4 *>(std::malloc(sizeof(float4) * n));
         uint32_t *kind = static_cast<uint32_t *>(std::malloc(sizeof(uint32_t) * n));
-        if(!geom || !matl || !kind) {
-            std::free(geom); std::free(matl); std::free(kind);
+        float4 *camera = static_cast<float4 *>(std::malloc(sizeof(float4) * n));
+        if(!geom || !matl || !kind || !camera) {
+            std::free(geom); std::free(matl); std::free(kind); std::free(camera);
             return fail(AEHIP_E_INVALID, "out of host memory staging %u spheres", n);
         }
         for(uint32_t i = 0; i < n; i++) {
@@ -1705,6 +1745,11 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
             geom[i] = make_float4(s.center[0], s.center[1], s.center[2], r * r);
             matl[i] = make_float4(s.albedo[0], s.albedo[1], s.albedo[2], s.param);
             kind[i] = s.material;
+            // camera entry: screen_sphere's oc and c for a ray from the camera, operation for operation
+            const float ocx = geom[i].x - vc.cam[0], ocy = geom[i].y - vc.cam[1], ocz = geom[i].z - vc.cam[2];
+            const float c = std::fmaf(ocz, ocz, std::fmaf(ocy, ocy, std::fmaf(ocx, ocx, -geom[i].w)));
+            const float u = (p.flags & AEHIP_FLAG_FAST) ? -c : std::fmaf(c, -(1.0f - 2.0f * kScreenMargin), geom[i].w * (3.0f * kScreenMargin));
+            camera[i] = make_float4(ocx, ocy, ocz, u);
         }
         b->all_terminal = true;
         for(uint32_t i = 0; i < n; i++) b->all_terminal = b->all_terminal && kind[i] == AEHIP_MAT_NORMAL;
@@ -1735,8 +1780,9 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
         hipError_t e = hipMemcpyAsync(b->d_geom, geom, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
         if(e == hipSuccess) e = hipMemcpyAsync(b->d_matl, matl, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
         if(e == hipSuccess) e = hipMemcpyAsync(b->d_kind, kind, sizeof(uint32_t) * n, hipMemcpyHostToDevice, b->stream);
+        if(e == hipSuccess) e = hipMemcpyAsync(b->d_camera, camera, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
         if(e == hipSuccess) e = hipStreamSynchronize(b->stream);
-        std::free(geom); std::free(matl); std::free(kind);
+        std::free(geom); std::free(matl); std::free(kind); std::free(camera);
         if(e != hipSuccess) return fail(AEHIP_E_HIP, "scene upload: %s", hipGetErrorString(e));
     }
 
