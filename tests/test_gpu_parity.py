@@ -352,6 +352,49 @@ def test_streamed_exact_pass_equals_the_per_lane_pass_at_1080p():
     assert st_a.rays / st_a.lane_slots > 1.5 * st_b.rays / st_b.lane_slots
 
 
+@pytest.mark.parametrize("fast", [False, True], ids=["exact", "fast"])
+@pytest.mark.parametrize("size,spp", [((200, 120), 5), ((960, 540), 2)])
+def test_streamed_pass_with_first_hits_equals_the_per_lane_pass(size, spp, fast):
+    """Lists of 1,024 spheres and more go through the first-hit pre-pass (camera entries, whole
+    waves) and the streamed kernel that shades a dealt path before its lane's first list walk.
+    Same paths as the one-lane-per-pixel pass: equal ray counts; exact build bit-identical, fast
+    build equal to float rounding (another order of summation)."""
+    import torch
+
+    sph = scenes.stress_scene(1100, 42)
+    w, h = size
+    argb_s, rgba_s, st_s = render_device(w, h, spp=spp, max_depth=6, seed=11, jitter=True, spheres=sph, count_rays=True, fast=fast)
+    back = rt.HipRaytracer(None)
+    try:
+        f = rt.FLAG_JITTER | rt.FLAG_COUNT_RAYS | rt.FLAG_NO_REGEN | (rt.FLAG_FAST if fast else 0)
+        assert back.setup(w, h, spp, 6, 11, f, rt.PASS_PATH, spheres=sph)
+        argb = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+        rgba = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        back.trace_device(argb.data_ptr(), rgba.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        st_l = back.stats()
+        rgba_l, argb_l = rgba.cpu().numpy(), argb.cpu().numpy().view(np.uint32)
+    finally:
+        back.close()
+    assert st_s.rays == st_l.rays
+    if fast:
+        assert float(np.max(np.abs(rgba_s - rgba_l))) <= 2e-6
+    else:
+        np.testing.assert_array_equal(rgba_s.view(np.uint32), rgba_l.view(np.uint32))
+        np.testing.assert_array_equal(argb_s, argb_l)
+
+
+def test_streamed_pass_with_first_hits_is_bit_identical_to_oracle():
+    sph = scenes.stress_scene(1100, 42)
+    w, h = 100, 52            # not a multiple of the 16x4 strip
+    kw = dict(spp=5, max_depth=6, seed=3, jitter=True, spheres=sph)
+    argb, rgba, st = render_device(w, h, count_rays=True, **kw)
+    o_argb, o_rgba, o_rays, _ = oracle.trace_paths(w, h, want_rgba=True, threads=8, **kw)
+    np.testing.assert_array_equal(argb, o_argb)
+    np.testing.assert_array_equal(rgba.view(np.uint32), o_rgba.view(np.uint32))
+    assert st.rays == o_rays
+
+
 # ------------------------------------------------------------------ one frame on several devices
 
 @pytest.mark.parametrize("bands", [1, 2, 3, 5])

@@ -29,6 +29,8 @@ CASES = {
     "stress2k_1080p_1spp_d4": (1920, 1080, 1, 4, lambda: scenes.stress_scene(2000, 42)),
     "stress2k_1080p_16spp_d4": (1920, 1080, 16, 4, lambda: scenes.stress_scene(2000, 42)),
     "divergence_1080p_16spp_d50": (1920, 1080, 16, 50, lambda: scenes.divergence_scene(300, 7)),
+    "divergence600_1080p_8spp_d50": (1920, 1080, 8, 50, lambda: scenes.divergence_scene(600, 7)),
+    "divergence1200_1080p_4spp_d50": (1920, 1080, 4, 50, lambda: scenes.divergence_scene(1200, 7)),
 }
 
 
