@@ -44,8 +44,8 @@ HBM_PEAK_GBS = 8000.0
 VALU_ISSUE_MEASURED = 54.0e12       # lane-instructions/s that back-to-back v_fma_f32 / v_mul_f32 sustain (tools/valu_peak.hip)
 # VALU wave-instructions one launch of the default workload (4K, 1024 spp, one GPU) executes:
 # SQ_INSTS_VALU per launch in the committed rocprofv3 --pmc summaries
-EXECUTED_VALU_WAVE_INSTRUCTIONS = {"fast": (1521852812, "profiles/r01_e_bench_fast.txt"),
-                                   "exact": (5272461844, "profiles/r01_e_bench_exact.txt")}
+EXECUTED_VALU_WAVE_INSTRUCTIONS = {"fast": (1521852812, "profiles/r01_f_bench_fast.txt"),
+                                   "exact": (5278682644, "profiles/r01_f_bench_exact.txt")}
 
 # Algorithmic FP32 flops of the default-scene path pass, counted on the reference's formulas with
 # div and sqrt = 1 flop each and integer / compare / convert = 0:
