@@ -2135,7 +2135,10 @@ int aehip_backend_trace(aehip_backend *b) {
         b->vc.row_count = r1 - r0;
         const int rc = launch(b, b->d_argb + offset, nullptr, b->stream);
         b->vc = whole;
-        if(rc != AEHIP_OK) return rc;
+        if(rc != AEHIP_OK) {
+            (void)hipStreamSynchronize(b->copy_stream);     // earlier parts' copies still write the staging buffer
+            return rc;
+        }
         paths += b->stats.paths;
         used[k] = true;
         AEHIP_CHECK(hipEventRecord(b->ev_part_done[k], b->stream));
