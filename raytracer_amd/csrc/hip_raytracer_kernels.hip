@@ -68,6 +68,7 @@ struct view_consts {
     uint32_t seed_hash;         // pcg_hash(seed), hoisted to the host
     uint32_t flags;
     uint32_t n_spheres;
+    float list_centre[3];       // origin of the coordinates the list prefilter works in (see prefilter_entry)
 };
 
 struct f3 {
@@ -535,6 +536,86 @@ __device__ __forceinline__ void intersect_chunk(const float4 *__restrict__ list,
     }
 }
 
+// List prefilter for rays from anywhere (8 operations a sphere; the screening value above takes
+// 10 because it forms oc = C - O first).  With everything measured from a point G in the middle
+// of the scene, Cc = C - G and Oc = O - G,
+//     h = d.Cc - d.Oc          c = |Cc|^2 - 2 Cc.Oc + |Oc|^2 - r*r
+// and what depends on the sphere alone (Cc and K = |Cc|^2 - r*r, tabulated at set-up) meets what
+// depends on the ray alone (d, d.Oc, -2 Oc, |Oc|^2, worked out once per segment) in two chains of
+// three fmas.  The expansion cancels where oc = C - O does not, so this value is only a filter:
+// its rounding errors (about 30 unit roundoffs of (|Cc| + |Oc| + r)^2) and the screening value's
+// own are covered five times over by a margin of kPrefilterMargin ((|Cc| + r)^2 + |Oc|^2), the
+// sphere's share of it folded into K and the ray's into the |Oc|^2 term -- it grows only for
+// spheres and rays far from G.  The exact build's screening margin is folded in the same way
+// (factor 1 - 2m on c, 3 m r*r in K).  A negative value therefore implies a negative screening
+// value; groups of four whose largest value is not negative go through the screening and
+// resolution above, from the sphere list, unchanged: results keep their bits.
+constexpr float kPrefilterMargin = 3.2e-5f;
+
+struct prefilter_ray {
+    f3 d;
+    float neg_d_oc;     // -(d.Oc)
+    f3 m2oc;            // -2 f Oc            (f = 1, exact build 1 - 2 kScreenMargin)
+    float q;            // (f - kPrefilterMargin) |Oc|^2
+};
+
+template <bool EXACT>
+__device__ __forceinline__ prefilter_ray make_prefilter_ray(const view_consts &vc, const f3 o, const f3 d) {
+    constexpr float f = EXACT ? 1.0f - 2.0f * kScreenMargin : 1.0f;
+    const f3 oc = {o.x - vc.list_centre[0], o.y - vc.list_centre[1], o.z - vc.list_centre[2]};
+    prefilter_ray r;
+    r.d = d;
+    r.neg_d_oc = -__builtin_fmaf(d.z, oc.z, __builtin_fmaf(d.y, oc.y, d.x * oc.x));
+    r.m2oc = f3{(-2.0f * f) * oc.x, (-2.0f * f) * oc.y, (-2.0f * f) * oc.z};
+    r.q = (f - kPrefilterMargin) * __builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, oc.x * oc.x));
+    return r;
+}
+
+// e = (Cc.xyz, K'), K' = f (|Cc|^2 - r*r) - [exact: 3 m r*r] - kPrefilterMargin (|Cc| + r)^2
+__device__ __forceinline__ float prefilter_entry(const float4 e, const prefilter_ray &r) {
+    const float h = __builtin_fmaf(r.d.z, e.z, __builtin_fmaf(r.d.y, e.y, __builtin_fmaf(r.d.x, e.x, r.neg_d_oc)));
+    const float v = __builtin_fmaf(e.z, r.m2oc.z, __builtin_fmaf(e.y, r.m2oc.y, __builtin_fmaf(e.x, r.m2oc.x, r.q)));
+    return __builtin_fmaf(h, h, -v) - e.w;
+}
+
+// The list walk of intersect_chunk over the prefilter table; `spheres` is the sphere list itself.
+template <bool EXACT>
+__device__ __forceinline__ void intersect_prefiltered(const view_consts &vc, const float4 *__restrict__ table,
+                                                      const float4 *__restrict__ spheres, uint32_t count, const f3 o, const f3 d,
+                                                      float a2, float a4, float &closest, int &hit) {
+    const prefilter_ray ray = make_prefilter_ray<EXACT>(vc, o, d);
+    auto test = [&](const sphere_group &e, uint32_t group) {
+        const float v0 = prefilter_entry(e.g0, ray), v1 = prefilter_entry(e.g1, ray);
+        const float v2 = prefilter_entry(e.g2, ray), v3 = prefilter_entry(e.g3, ray);
+        if(__builtin_fmaxf(__builtin_fmaxf(v0, v1), __builtin_fmaxf(v2, v3)) >= 0.0f)
+            test_group<EXACT, false>(load_group(spheres, group), nullptr, static_cast<int>(group * 4u), o, d, a2, a4, closest, hit);
+    };
+    const uint32_t groups = count / 4u;
+    uint32_t g = 0;
+    if(groups > 0) {
+        sphere_group A = load_group(table, 0);
+        while(g + 2 <= groups) {
+            const sphere_group B = load_group(table, g + 1);
+            test(A, g);
+            A = load_group(table, min(g + 2, groups - 1));      // clamped: the last fetch may repeat a group
+            test(B, g + 1);
+            g += 2;
+        }
+        if(g < groups) {
+            test(A, g);
+            g++;
+        }
+    }
+    for(uint32_t i = g * 4u; i < count; i++) {
+        if(prefilter_entry(table[i], ray) >= 0.0f) {
+            const float4 s = spheres[i];
+            float h;
+            const float k = screen_sphere<EXACT>(s, o, d, h);
+            resolve_sphere<EXACT>(s, static_cast<int>(i), k, h, o, d, a2, a4, closest, hit);
+        }
+    }
+}
+
 // Shades the hit (or miss) of the current segment.  Returns true when the path ended with
 // radiance L; false when it continues with ps updated.
 template <bool EXACT>
@@ -860,8 +941,9 @@ __global__ __launch_bounds__(kBlock) void first_hit_kernel(view_consts vc, const
     if((vc.flags & AEHIP_FLAG_COUNT_RAYS) && lane == 0) atomicAdd(ray_counter + 1, 64ull * count);
 }
 
-template <bool EXACT>
+template <bool EXACT, bool PREFILTER>
 __global__ __launch_bounds__(kBlock) void path_stream_kernel(view_consts vc, const float4 *__restrict__ geom,
+                                                             const float4 *__restrict__ prefilter_list,
                                                              const float4 *__restrict__ matl,
                                                              const uint32_t *__restrict__ kind,
                                                              const uint32_t *__restrict__ sample_terms,
@@ -965,7 +1047,8 @@ __global__ __launch_bounds__(kBlock) void path_stream_kernel(view_consts vc, con
             }
             float closest = 3.402823466e+38f;
             int hit = -1;
-            intersect_chunk<EXACT>(geom, vc.n_spheres, 0, ps.o, ps.d, a2, a4, closest, hit);
+            if constexpr(PREFILTER) intersect_prefiltered<EXACT>(vc, prefilter_list, geom, vc.n_spheres, ps.o, ps.d, a2, a4, closest, hit);
+            else intersect_chunk<EXACT>(geom, vc.n_spheres, 0, ps.o, ps.d, a2, a4, closest, hit);
             nrays++;
             f3 L;
             if(shade_segment<EXACT>(vc, y, hit, closest, geom, matl, kind, ps, L)) {
@@ -991,8 +1074,9 @@ __global__ __launch_bounds__(kBlock) void path_stream_kernel(view_consts vc, con
 // to `deal_rounds` times -- so that lanes whose path ends at its first hit (most camera rays that
 // see the sky) get another path before the walk instead of idling through it -- and then the
 // walk for every lane whose ray has no hit yet.
-template <bool EXACT>
+template <bool EXACT, bool PREFILTER>
 __global__ __launch_bounds__(kBlock) void path_stream_first_hits_kernel(view_consts vc, const float4 *__restrict__ geom,
+                                                                        const float4 *__restrict__ prefilter_list,
                                                              const float4 *__restrict__ matl,
                                                              const uint32_t *__restrict__ kind,
                                                              const uint32_t *__restrict__ sample_terms,
@@ -1109,7 +1193,8 @@ __global__ __launch_bounds__(kBlock) void path_stream_first_hits_kernel(view_con
         }
         hit_t = 3.402823466e+38f;
         hit_index = -1;
-        intersect_chunk<EXACT>(geom, vc.n_spheres, 0, ps.o, ps.d, a2, a4, hit_t, hit_index);
+        if constexpr(PREFILTER) intersect_prefiltered<EXACT>(vc, prefilter_list, geom, vc.n_spheres, ps.o, ps.d, a2, a4, hit_t, hit_index);
+        else intersect_chunk<EXACT>(geom, vc.n_spheres, 0, ps.o, ps.d, a2, a4, hit_t, hit_index);
         nrays++;
     };
 
@@ -1601,6 +1686,8 @@ struct aehip_backend {
 
     float4 *d_geom = nullptr;                // n x (cx, cy, cz, r*r)
     float4 *d_camera = nullptr;              // n x (oc.xyz, u): camera entries, see screen_camera_entry
+    float4 *d_prefilter = nullptr;           // n x (Cc.xyz, K'): prefilter entries, see prefilter_entry
+    bool prefilter_pays = false;             // few enough rays pass it for it to be worth its 8 operations a sphere
     float4 *d_matl = nullptr;                // n x (albedo rgb, param)
     uint32_t *d_kind = nullptr;              // n x material id
     uint32_t scene_capacity = 0;
@@ -1718,8 +1805,17 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
             int per_cu = 0;
             const bool first_hits = vc.n_spheres >= kFirstHitsMinSpheres;
             const uint32_t deal_rounds = kDealRounds;
-            if(first_hits) func = exact ? reinterpret_cast<const void *>(path_stream_first_hits_kernel<true>) : reinterpret_cast<const void *>(path_stream_first_hits_kernel<false>);
-            else func = exact ? reinterpret_cast<const void *>(path_stream_kernel<true>) : reinterpret_cast<const void *>(path_stream_kernel<false>);
+            // the list prefilter (8 operations a sphere) pays where the screening value costs 12 (exact
+            // build; the fast build's 10 are not enough to cover the groups that pass) and few groups
+            // of four pass it in any lane (set-up's estimate)
+            const bool prefilter = exact && b->prefilter_pays;
+            if(first_hits) {
+                if(exact) func = prefilter ? reinterpret_cast<const void *>(path_stream_first_hits_kernel<true, true>) : reinterpret_cast<const void *>(path_stream_first_hits_kernel<true, false>);
+                else func = prefilter ? reinterpret_cast<const void *>(path_stream_first_hits_kernel<false, true>) : reinterpret_cast<const void *>(path_stream_first_hits_kernel<false, false>);
+            } else {
+                if(exact) func = prefilter ? reinterpret_cast<const void *>(path_stream_kernel<true, true>) : reinterpret_cast<const void *>(path_stream_kernel<true, false>);
+                else func = prefilter ? reinterpret_cast<const void *>(path_stream_kernel<false, true>) : reinterpret_cast<const void *>(path_stream_kernel<false, false>);
+            }
             AEHIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, func, kBlock, 0));
             const uint32_t strips = ((vc.width + kTileW - 1) / kTileW) * ((vc.row_count + 3u) / 4u);
             const uint32_t resident = static_cast<uint32_t>(per_cu > 0 ? per_cu : 1) * static_cast<uint32_t>(b->cu_count);
@@ -1740,11 +1836,10 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
                     if(exact) hipLaunchKernelGGL(first_hit_kernel<true>, first_grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_camera, b->d_sample_terms, b->d_radiance, begin, count, b->d_rays);
                     else hipLaunchKernelGGL(first_hit_kernel<false>, first_grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_camera, b->d_sample_terms, b->d_radiance, begin, count, b->d_rays);
                 }
-                void *args[] = {const_cast<view_consts *>(&vc), &b->d_geom, &b->d_matl, &b->d_kind, &b->d_sample_terms, &b->d_radiance,
-                                const_cast<uint32_t *>(&begin), const_cast<uint32_t *>(&count), &b->d_rays, nullptr,
-                                const_cast<uint32_t *>(&unit_batch), const_cast<uint32_t *>(&deal_rounds)};
                 uint32_t *queue = reinterpret_cast<uint32_t *>(b->d_rays + 2);
-                args[9] = &queue;
+                void *args[] = {const_cast<view_consts *>(&vc), &b->d_geom, &b->d_prefilter, &b->d_matl, &b->d_kind, &b->d_sample_terms,
+                                &b->d_radiance, const_cast<uint32_t *>(&begin), const_cast<uint32_t *>(&count), &b->d_rays, &queue,
+                                const_cast<uint32_t *>(&unit_batch), const_cast<uint32_t *>(&deal_rounds)};
                 // (the kernel without first hits has no last parameter and ignores the extra entry)
                 AEHIP_CHECK(hipLaunchKernel(func, dim3(groups), dim3(kBlock), args, 0, stream));
                 hipLaunchKernelGGL(resolve_block_kernel, dim3((strips + 3u) / 4u), dim3(kBlock), 0, stream, vc, b->d_radiance, b->d_totals,
@@ -1948,9 +2043,11 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
         if(b->d_matl) (void)hipFree(b->d_matl);
         if(b->d_kind) (void)hipFree(b->d_kind);
         if(b->d_camera) (void)hipFree(b->d_camera);
-        b->d_geom = nullptr; b->d_matl = nullptr; b->d_kind = nullptr; b->d_camera = nullptr; b->scene_capacity = 0;
+        if(b->d_prefilter) (void)hipFree(b->d_prefilter);
+        b->d_geom = nullptr; b->d_matl = nullptr; b->d_kind = nullptr; b->d_camera = nullptr; b->d_prefilter = nullptr; b->scene_capacity = 0;
         AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_geom), sizeof(float4) * n));
         AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_camera), sizeof(float4) * n));
+        AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_prefilter), sizeof(float4) * n));
         AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_matl), sizeof(float4) * n));
         AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_kind), sizeof(uint32_t) * n));
         b->scene_capacity = n;
@@ -1960,8 +2057,9 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
         float4 *matl = static_cast<float4 *>(std::malloc(sizeof(float4) * n));
         uint32_t *kind = static_cast<uint32_t *>(std::malloc(sizeof(uint32_t) * n));
         float4 *camera = static_cast<float4 *>(std::malloc(sizeof(float4) * n));
-        if(!geom || !matl || !kind || !camera) {
-            std::free(geom); std::free(matl); std::free(kind); std::free(camera);
+        float4 *prefilter = static_cast<float4 *>(std::malloc(sizeof(float4) * n));
+        if(!geom || !matl || !kind || !camera || !prefilter) {
+            std::free(geom); std::free(matl); std::free(kind); std::free(camera); std::free(prefilter);
             return fail(AEHIP_E_INVALID, "out of host memory staging %u spheres", n);
         }
         for(uint32_t i = 0; i < n; i++) {
@@ -1975,6 +2073,47 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
             const float c = std::fmaf(ocz, ocz, std::fmaf(ocy, ocy, std::fmaf(ocx, ocx, -geom[i].w)));
             const float u = (p.flags & AEHIP_FLAG_FAST) ? -c : std::fmaf(c, -(1.0f - 2.0f * kScreenMargin), geom[i].w * (3.0f * kScreenMargin));
             camera[i] = make_float4(ocx, ocy, ocz, u);
+        }
+        {
+            // prefilter entries: centres measured from the component-wise median of the centres (a
+            // far ground sphere does not drag it away from where the small spheres are), K' in double
+            std::vector<float> axis(n);
+            for(int k = 0; k < 3; k++) {
+                for(uint32_t i = 0; i < n; i++) axis[i] = k == 0 ? geom[i].x : k == 1 ? geom[i].y : geom[i].z;
+                std::nth_element(axis.begin(), axis.begin() + n / 2, axis.end());
+                vc.list_centre[k] = std::isfinite(axis[n / 2]) ? axis[n / 2] : 0.0f;
+            }
+            const double f = (p.flags & AEHIP_FLAG_FAST) ? 1.0 : 1.0 - 2.0 * static_cast<double>(kScreenMargin);
+            const double m3 = (p.flags & AEHIP_FLAG_FAST) ? 0.0 : 3.0 * static_cast<double>(kScreenMargin);
+            std::vector<double> distance2(n), section(n);
+            for(uint32_t i = 0; i < n; i++) {
+                const float cx = geom[i].x - vc.list_centre[0], cy = geom[i].y - vc.list_centre[1], cz = geom[i].z - vc.list_centre[2];
+                const double cc = static_cast<double>(cx) * cx + static_cast<double>(cy) * cy + static_cast<double>(cz) * cz;
+                const double r2 = geom[i].w, reach = std::sqrt(cc) + std::sqrt(r2);
+                const double k = f * (cc - r2) - m3 * r2 - static_cast<double>(kPrefilterMargin) * reach * reach;
+                // rounded down: K' enters the filter's value with a minus sign
+                float kf = static_cast<float>(k);
+                if(static_cast<double>(kf) > k) kf = std::nextafterf(kf, -INFINITY);
+                prefilter[i] = make_float4(cx, cy, cz, kf);
+                distance2[i] = cc;
+                section[i] = r2 + static_cast<double>(kPrefilterMargin) * reach * reach;     // the filter's cross-section / pi
+            }
+            // Does the filter pay?  A group of four goes on to the full screening when any of the
+            // wave's 64 rays passes any of its spheres, so it must be rare per ray and sphere: a
+            // line through a scene of radius R passes a sphere with probability ~ section / R^2
+            // (R: the 90th percentile of the centres' distances, so that a far ground sphere counts
+            // as "always passes" and nothing more).  Measured: 10,000 small spheres in a 40-unit
+            // slab (2 % of the groups) 46.9 -> 39.7 ms; 1,200 in a dense cloud (half of them) 37.2 -> 42.1.
+            std::vector<double> sorted(distance2);
+            std::nth_element(sorted.begin(), sorted.begin() + (n - 1) * 9 / 10, sorted.end());
+            const double scene_r2 = std::max(sorted[(n - 1) * 9 / 10], 1e-12);
+            double passing = 0.0;                   // expected number of groups that pass in some lane
+            for(uint32_t i = 0; i < n; i += 4) {
+                double q = 0.0;
+                for(uint32_t j = i; j < std::min(i + 4u, n); j++) q += section[j] / scene_r2;
+                passing += std::min(1.0, 64.0 * q);
+            }
+            b->prefilter_pays = passing <= 0.1 * ((n + 3u) / 4u);
         }
         b->all_terminal = true;
         for(uint32_t i = 0; i < n; i++) b->all_terminal = b->all_terminal && kind[i] == AEHIP_MAT_NORMAL;
@@ -2006,8 +2145,9 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
         if(e == hipSuccess) e = hipMemcpyAsync(b->d_matl, matl, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
         if(e == hipSuccess) e = hipMemcpyAsync(b->d_kind, kind, sizeof(uint32_t) * n, hipMemcpyHostToDevice, b->stream);
         if(e == hipSuccess) e = hipMemcpyAsync(b->d_camera, camera, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
+        if(e == hipSuccess) e = hipMemcpyAsync(b->d_prefilter, prefilter, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
         if(e == hipSuccess) e = hipStreamSynchronize(b->stream);
-        std::free(geom); std::free(matl); std::free(kind); std::free(camera);
+        std::free(geom); std::free(matl); std::free(kind); std::free(camera); std::free(prefilter);
         if(e != hipSuccess) return fail(AEHIP_E_HIP, "scene upload: %s", hipGetErrorString(e));
     }
 

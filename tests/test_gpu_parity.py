@@ -395,6 +395,31 @@ def test_streamed_pass_with_first_hits_is_bit_identical_to_oracle():
     assert st.rays == o_rays
 
 
+@pytest.mark.parametrize("case", ["far_camera", "far_outlier", "oblique"])
+def test_list_prefilter_never_loses_a_hit(case):
+    """The exact build's streamed pass filters long sparse lists with a cheaper value whose
+    rounding errors grow with the distance from the middle of the scene.  Camera far away or off
+    to the side, huge and far outliers in the list: still the oracle's image and ray count, bit for bit."""
+    sph = scenes.stress_scene(1100, 42)
+    kw = dict(spp=3, max_depth=6, seed=9, jitter=True)
+    if case == "far_camera":
+        kw["cam"] = (2.0, -1.0, 120.0)
+    elif case == "far_outlier":
+        sph = sph.copy()
+        sph["center"][7] = (0.0, -5000.0, -30.0)
+        sph["radius"][7] = 4985.0                      # a ground that cuts through the slab
+        sph["center"][8] = (900.0, 30.0, -800.0)
+        sph["radius"][8] = 0.5
+    else:
+        kw["cam"] = (25.0, -18.0, 35.0)
+    w, h = 112, 60
+    argb, rgba, st = render_device(w, h, count_rays=True, spheres=sph, **kw)
+    o_argb, o_rgba, o_rays, _ = oracle.trace_paths(w, h, want_rgba=True, threads=8, spheres=sph, **kw)
+    np.testing.assert_array_equal(rgba.view(np.uint32), o_rgba.view(np.uint32))
+    np.testing.assert_array_equal(argb, o_argb)
+    assert st.rays == o_rays
+
+
 # ------------------------------------------------------------------ one frame on several devices
 
 @pytest.mark.parametrize("bands", [1, 2, 3, 5])
