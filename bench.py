@@ -358,6 +358,28 @@ def aux_measurements(rt, torch, stream):
                      "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": nbytes,
                      "note": "33 MB store per launch; launches back to back, so the figure includes launch gaps"},
     }
+    # the drop-in call itself: setup once, trace() into host memory (render in parts, device ->
+    # pinned staging -> the caller's buffer overlapped with it); PCIe-inclusive, never `value`
+    import numpy as np
+    import time as _time
+    for mode in ("fast", "exact"):
+        fb = np.zeros((HEIGHT, WIDTH), dtype=np.uint32)
+        back = rt.HipRaytracer(fb)
+        back.setup(WIDTH, HEIGHT, spp=1024, max_depth=8, seed=1, flags=rt.FLAG_JITTER | (rt.FLAG_FAST if mode == "fast" else 0),
+                   pass_=rt.PASS_PATH)
+        for _ in range(3):
+            back.trace()
+        calls = 10 if mode == "fast" else 5
+        t0 = _time.perf_counter()
+        for _ in range(calls):
+            back.trace()
+        wall = (_time.perf_counter() - t0) / calls * 1e3
+        st = back.stats()
+        back.close()
+        out[f"host_buffer_call_4k_1024spp_{mode}"] = {
+            "ms_per_call": wall, "mpaths_per_s": WIDTH * HEIGHT * 1024 / wall / 1e3, "kernel_ms": st.kernel_ms,
+            "copy_tail_ms": st.copy_ms, "note": "aehip_backend_trace: wall time seen by the caller, frame delivered in host memory",
+        }
     # brute-force list (config "~10k random spheres"): every ray tests every sphere, 18 flop per test
     # as the reference writes it.  Depth 1: camera rays only, every lane busy; the kernel walks the
     # table of per-sphere camera constants (4 operations a test).  Depth 4: the streamed pass, rays
