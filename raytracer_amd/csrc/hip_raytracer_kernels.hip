@@ -1687,6 +1687,7 @@ struct aehip_backend {
     float4 *d_geom = nullptr;                // n x (cx, cy, cz, r*r)
     float4 *d_camera = nullptr;              // n x (oc.xyz, u): camera entries, see screen_camera_entry
     float4 *d_prefilter = nullptr;           // n x (Cc.xyz, K'): prefilter entries, see prefilter_entry
+    float last_trace_render_ms = 0.0f;       // render time of the last aehip_backend_trace of the current request
     bool prefilter_pays = false;             // few enough rays pass it for it to be worth its 8 operations a sphere
     float4 *d_matl = nullptr;                // n x (albedo rgb, param)
     uint32_t *d_kind = nullptr;              // n x material id
@@ -2207,6 +2208,7 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
     }
 
     b->params = p;
+    b->last_trace_render_ms = 0.0f;
     b->ready = true;
     return AEHIP_OK;
 }
@@ -2257,12 +2259,19 @@ int aehip_backend_trace(aehip_backend *b) {
     const uint32_t width = b->vc.width, rows = b->vc.row_count;
     const bool in_parts = b->vc.tile_rows == 0 && !(b->vc.flags & AEHIP_FLAG_COUNT_RAYS) && rows >= 64u && pixels >= (1u << 20) &&
                           !takes_streamed_pass(b);
-    const int parts = in_parts ? kTraceParts : 1;
+    // In a render much longer than the copies (known from this request's previous call) a part's
+    // copies fit beside a following part a third its size, and every extra launch costs a round
+    // of waves: three parts, each about a third of the one before.
+    const double copies_ms = static_cast<double>(pixels) * sizeof(uint32_t) / 1.5e7;       // ~15 GB/s, both copies in a row
+    const bool long_render = b->last_trace_render_ms > 2.0 * copies_ms;
+    const int parts = !in_parts ? 1 : long_render ? 3 : kTraceParts;
     const view_consts whole = b->vc;
     // part k is band rows [part_begin(k), part_begin(k + 1)), cut on multiples of 16 rows (the tallest workgroup tile)
     auto part_begin = [&](int k) -> uint32_t {
         if(k <= 0) return 0u;
-        return k >= parts ? rows : static_cast<uint32_t>(static_cast<uint64_t>(rows) * kTracePartEnd[k - 1] / 32u) / 16u * 16u;
+        if(k >= parts) return rows;
+        const uint32_t end = long_render ? (k == 1 ? 22u : 29u) : kTracePartEnd[k - 1];
+        return static_cast<uint32_t>(static_cast<uint64_t>(rows) * end / 32u) / 16u * 16u;
     };
     uint64_t paths = 0;
     bool used[kTraceParts] = {};
@@ -2300,6 +2309,7 @@ int aehip_backend_trace(aehip_backend *b) {
     b->timed_on_own_stream = true;
     float ms = 0.0f;
     if(hipEventElapsedTime(&ms, b->ev_end, b->ev_copy) == hipSuccess) b->stats.copy_ms = ms;
+    if(hipEventElapsedTime(&ms, b->ev_begin, b->ev_end) == hipSuccess) b->last_trace_render_ms = ms;
     return AEHIP_OK;
 }
 

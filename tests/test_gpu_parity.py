@@ -694,3 +694,24 @@ def test_host_buffer_call_in_parts_equals_the_single_launch(case):
     dev, _, st_dev = render_device(w, h, want_rgba=False, **kw)
     np.testing.assert_array_equal(host, dev)
     assert st.paths == st_dev.paths
+
+
+def test_host_buffer_call_repeated_with_a_long_render_equals_the_single_launch():
+    """The second call of a request whose render is long beside its copies cuts the band into
+    three shrinking parts instead of five; same image both times."""
+    w, h, spp = 1400, 1000, 1024
+    fb = np.zeros((h, w), dtype=np.uint32)
+    back = rt.HipRaytracer(fb)
+    try:
+        assert back.setup(w, h, spp, 1, 1, rt.FLAG_JITTER, rt.PASS_PATH), back.last_error()
+        back.trace()
+        first = fb.copy()
+        fb[:] = 0
+        back.trace()
+        st = back.stats()
+    finally:
+        back.close()
+    dev, _, _ = render_device(w, h, want_rgba=False, spp=spp, max_depth=1, jitter=True)
+    np.testing.assert_array_equal(first, dev)
+    np.testing.assert_array_equal(fb, dev)
+    assert st.paths == w * h * spp
