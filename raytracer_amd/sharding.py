@@ -104,12 +104,15 @@ class BandGather:
                     rows = band_image_rows(b)
                     src[torch.tensor(rows, dtype=torch.int64)] = torch.arange(len(rows), dtype=torch.int64) + r * self.max_rows
                 self._row_source = src.to(device)
+        if not self.collective:
+            # one rank: the band is the image, rendered in place; nothing to gather or copy
+            self.locals = [self.image[: self.max_rows], self.image[: self.max_rows]]
+            self.local = self.locals[0]
         self._pending = [None, None]
-        # per buffer: event after which the buffer may be rendered into again; single rank: event of
-        # the last copy into the image (an event is re-recorded freely: a wait holds the record it saw)
-        self._events = [torch.cuda.Event() for _ in range(3)] if self.on_gpu else None
+        # per buffer: event after which the buffer may be rendered into again (an event is
+        # re-recorded freely: a wait holds the record it saw)
+        self._events = [torch.cuda.Event() for _ in range(2)] if self.on_gpu else None
         self._free = [None, None]
-        self._copied = None
 
     # ------------------------------------------------------------------ blocking form
 
@@ -157,13 +160,7 @@ class BandGather:
     def _start(self, slot: int, async_op: bool):
         src = self.locals[slot]
         if not self.collective:
-            if self.on_gpu and self._copied is not None:
-                torch.cuda.current_stream().wait_event(self._copied)     # frames reach the image in order
-            self.image[: self.rows].copy_(src[: self.rows])
-            if self.on_gpu:
-                self._copied = self._events[2]
-                self._copied.record()
-            return None
+            return None                 # rendered straight into the image
         return dist.gather(src, self.parts if self.rank == self.dst else None, dst=self.dst, async_op=async_op)
 
     def _assemble(self) -> torch.Tensor | None:
