@@ -153,11 +153,18 @@ def main():
     dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    # BENCH_FORCE_COLLECTIVE=1: the multi-rank code path (process group, two render streams,
+    # asynchronous gather, row reorder, barriers) with however many ranks there are -- a one-rank
+    # RCCL group rehearses it on a one-GPU box
+    grouped = world > 1 or os.environ.get("BENCH_FORCE_COLLECTIVE") == "1"
+    if grouped:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
         if share:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     # everything runs on side streams: the library treats the null stream as "use your own and
     # wait", and launches are to queue back to back without the host in between.  With several
@@ -170,10 +177,10 @@ def main():
         sides = None                    # gloo's device-tensor path is slow off the default stream
         stream = None
     else:
-        sides = [torch.cuda.Stream(device=device) for _ in range(2 if world > 1 else 1)]
+        sides = [torch.cuda.Stream(device=device) for _ in range(2 if grouped else 1)]
         torch.cuda.set_stream(sides[0])
         stream = sides[0].cuda_stream
-    gather = BandGather(WIDTH, HEIGHT, device)
+    gather = BandGather(WIDTH, HEIGHT, device, always_collective=grouped)
     overlap = not share                 # gloo's asynchronous gather of device tensors does not complete here
 
     verified = {}
@@ -189,7 +196,7 @@ def main():
             back.trace_device(gather.local.data_ptr(), None, stream)
             gather.gather()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -208,7 +215,7 @@ def main():
         if sides is not None:
             torch.cuda.set_stream(sides[0])
         gather.finish()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -219,7 +226,7 @@ def main():
         else:
             kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
         t = torch.tensor([elapsed, kernel_ms * 1e-3], dtype=torch.float64, device=device)
-        if world > 1:
+        if grouped:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         st = back.stats()
         back.close()
@@ -327,7 +334,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 
