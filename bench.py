@@ -22,8 +22,14 @@ The line also carries
                 timed on this host's cores on a bounded sample of the same frame, plus the real
                 reference binary's 1-sample figure where oracle/_ref was shipped,
   aux           (N=1, unless --no-aux) the reference-pinned primary pass at 4K against HBM store
-                bandwidth, the 10,000-sphere brute-force scene against the FP32 vector peak, and the
-                divergence-heavy scene's lane utilisation with and without path regeneration.
+                bandwidth, the host-buffer call's wall time, the 10,000-sphere brute-force scene
+                against the FP32 vector peak, and the divergence-heavy scene's lane utilisation with
+                and without path regeneration.
+
+With several ranks consecutive frames go to two streams in turn and the gather of a frame runs
+beside the next frame's rendering (raytracer_amd/sharding.py).  Rehearsals on a one-GPU box:
+BENCH_FORCE_COLLECTIVE=1 runs that loop with a one-rank RCCL group; BENCH_SHARE_GPUS=1 under
+torch.distributed.run lets several ranks share the GPU, with gloo in RCCL's place.
 """
 import argparse
 import json
