@@ -115,3 +115,21 @@ def test_overlapped_gather_delivers_the_last_frame(tmp_path, world, size):
     image = np.load(out)
     want = next(e["sha256"] for e in META["images"] if (e["width"], e["height"]) == (width, height))
     assert hashlib.sha256(image.tobytes()).hexdigest() == want
+
+
+def test_single_rank_renders_straight_into_the_image():
+    """Without a process group there is nothing to gather: both band buffers are the image itself
+    and the frame loop's calls do no copying."""
+    assert not dist.is_initialized()
+    g = BandGather(32, 12, torch.device("cpu"))
+    assert g.band == dict(row_begin=0, row_count=12, tile_rows=0, tile_stride=0)
+    assert not g.collective
+    for frame in range(3):
+        band = g.begin(frame)
+        assert band.data_ptr() == g.image.data_ptr() and band.shape == (12, 32)
+        band.fill_(frame + 1)
+        g.submit(frame)
+    image = g.finish()
+    assert image is g.image and bool((image == 3).all())
+    g.local.fill_(7)
+    assert bool((g.gather() == 7).all())
