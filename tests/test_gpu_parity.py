@@ -492,6 +492,20 @@ def test_tiled_bands_reassemble_the_4k_reference_image(gpus):
     assert sha(render_tiled(w, h, gpus, 4, spp=1, max_depth=8, pass_=rt.PASS_PATH)) == want
 
 
+@pytest.mark.parametrize("fast", [True, False], ids=["fast", "exact"])
+def test_headline_frame_is_the_same_on_1_2_4_8_gpus(fast):
+    """The benchmark's own configuration at full size (3840x2160, 1024 jittered samples): the tiles
+    dealt to 2, 4 and 8 ranks, rendered rank by rank and put back in image order, are bit for bit
+    the frame one launch renders.  Sample keys depend on the absolute pixel and the sample only."""
+    w, h = 3840, 2160
+    kw = dict(spp=1024, max_depth=8, seed=1, jitter=True, fast=fast)
+    whole, st = rt.render(w, h, **kw)
+    assert st.paths == w * h * 1024
+    digest = sha(whole)
+    for world in (2, 4, 8):
+        assert sha(render_tiled(w, h, world, 4, **kw)) == digest, f"{world} ranks"
+
+
 @pytest.mark.parametrize("world,tile_rows,size", [(2, 4, (128, 72)), (3, 5, (130, 75)), (4, 16, (100, 200)), (3, 1, (33, 47)),
                                                    (2, 1, (255, 3))])
 def test_tiled_bands_equal_the_whole_image(world, tile_rows, size):
