@@ -614,6 +614,39 @@ def test_bands_of_the_headline_frame_fast_build_within_one_code_value_of_the_ora
     assert int((diff.max(axis=-1) > 0).sum()) <= 0.0005 * w * row_count
 
 
+@pytest.mark.parametrize("case", ["stress10k_depth4", "stress10k_depth1", "divergence_depth50"])
+def test_bands_of_the_full_size_scene_configurations_equal_the_oracle(case):
+    """The 10,000-sphere brute-force scene and the depth-50 mixed-material scene at their
+    benchmark size (1920x1080): a band of the frame, exact build, is the CPU oracle's band bit for
+    bit, ray count included -- through the first-hit pre-pass, the list prefilter and the streamed
+    pass (10,000 spheres, depth 4), the camera table of the per-lane pass (depth 1) and the
+    streamed pass with the plain list walk (301 spheres)."""
+    w, h = 1920, 1080
+    if case == "divergence_depth50":
+        kw = dict(spp=4, max_depth=50, seed=7, jitter=True, spheres=scenes.divergence_scene(300, 7))
+        row_begin, row_count = 600, 8
+    else:
+        kw = dict(spp=2, max_depth=4 if case.endswith("depth4") else 1, seed=1, jitter=True, spheres=scenes.stress_scene(10000, 42))
+        row_begin, row_count = 536, 4
+    want, _, rays, _ = oracle.trace_paths(w, h, row_begin=row_begin, row_count=row_count, threads=16, **kw)
+    got, st = rt.render(w, h, row_begin=row_begin, row_count=row_count, count_rays=True, **kw)
+    np.testing.assert_array_equal(got, want)
+    assert st.rays == rays
+
+
+@pytest.mark.parametrize("fast", [True, False], ids=["fast", "exact"])
+def test_full_size_scene_configurations_are_the_same_on_1_and_4_gpus(fast):
+    """The 10,000-sphere scene (1080p, 4 samples, depth 4) and the depth-50 scene (1080p, 8 samples)
+    at benchmark size: the tiles dealt to 4 ranks, rendered rank by rank, are the whole frame's
+    bits -- the streamed pass stores every path's radiance under its pixel and sample, so neither
+    the launch's shape nor which wave finishes first can change a sum."""
+    w, h = 1920, 1080
+    for kw in (dict(spp=4, max_depth=4, seed=1, spheres=scenes.stress_scene(10000, 42)),
+               dict(spp=8, max_depth=50, seed=7, spheres=scenes.divergence_scene(300, 7))):
+        whole, _ = rt.render(w, h, jitter=True, fast=fast, **kw)
+        assert sha(render_tiled(w, h, 4, 4, jitter=True, fast=fast, **kw)) == sha(whole)
+
+
 # ------------------------------------------------------------------ randomised differential test
 
 def random_scene(rng, n):
