@@ -64,6 +64,10 @@ __global__ __launch_bounds__(256) void probe(float *out, float seed, unsigned us
             if constexpr(KIND == 23) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(u[i]) : "v"(um));
             if constexpr(KIND == 24) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(u[i]) : "v"(a[i]), "v"(m));
             if constexpr(KIND == 25) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(u[i]) : "v"(um));
+            if constexpr(KIND == 26) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(m), "v"(c));        // scalar-register operand
+            if constexpr(KIND == 27) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "s"(m), "v"(c));            // VOP2 form, scalar operand
+            if constexpr(KIND == 28) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+            if constexpr(KIND == 29) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(a[i]) : "s"(m));
             if constexpr(KIND == 14) a[i] = m / a[i];                    // IEEE-correct division
             if constexpr(KIND == 15) a[i] = __builtin_sqrtf(a[i] + m);   // IEEE-correct sqrt (+1 add)
         }
@@ -129,6 +133,10 @@ int main() {
     run<23>("pk_mul_f16", 2, d_out);
     run<24>("cvt_pkrtz", 0, d_out);
     run<25>("pk_max_f16", 0, d_out);
+    run<26>("fma_sgpr_op", 2, d_out);
+    run<27>("fmac_sgpr_op", 2, d_out);
+    run<28>("max3", 0, d_out);
+    run<29>("sub_sgpr_op", 1, d_out);
     run<14>("div_ieee", 1, d_out);
     run<15>("sqrt_ieee", 1, d_out);
     HIPCHK(hipFree(d_out));
