@@ -22,8 +22,12 @@ constexpr int kAcc = 16;
         }                                                                             \
     } while(0)
 
+struct scalar_bank {
+    float v[16];
+};
+
 template <int KIND>
-__global__ __launch_bounds__(256) void probe(float *out, float seed, unsigned useed) {
+__global__ __launch_bounds__(256) void probe(float *out, float seed, unsigned useed, scalar_bank bank) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     float a[kAcc];
     v2f p[kAcc];
@@ -64,10 +68,17 @@ __global__ __launch_bounds__(256) void probe(float *out, float seed, unsigned us
             if constexpr(KIND == 23) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(u[i]) : "v"(um));
             if constexpr(KIND == 24) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(u[i]) : "v"(a[i]), "v"(m));
             if constexpr(KIND == 25) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(u[i]) : "v"(um));
-            if constexpr(KIND == 26) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(m), "v"(c));        // scalar-register operand
-            if constexpr(KIND == 27) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "s"(m), "v"(c));            // VOP2 form, scalar operand
+            if constexpr(KIND == 26) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(bank.v[0]), "v"(c));  // one scalar-register operand, the same every time
+            if constexpr(KIND == 27) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "s"(bank.v[0]), "v"(c));     // VOP2 form
             if constexpr(KIND == 28) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
-            if constexpr(KIND == 29) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(a[i]) : "s"(m));
+            if constexpr(KIND == 29) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(a[i]) : "s"(bank.v[0]));
+            if constexpr(KIND == 30) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(bank.v[i % 16]), "v"(c));  // a different scalar register each time
+            if constexpr(KIND == 31) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "s"(bank.v[i % 16]), "v"(c));
+            if constexpr(KIND == 32) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(bank.v[i / 4]), "v"(c));   // each scalar register four times in a row
+            if constexpr(KIND == 33) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(bank.v[i / 2]), "v"(c));   // twice in a row
+            if constexpr(KIND == 34) asm volatile("v_add_u32 %0, %1, %0" : "+v"(u[i]) : "s"(bank.v[i % 16]));
+            if constexpr(KIND == 35) asm volatile("v_mov_b32 %0, %1" : "=v"(u[i]) : "s"(bank.v[i % 16]));
+            if constexpr(KIND == 36) asm volatile("v_mov_b32 %0, %1" : "=v"(u[i]) : "v"(um));
             if constexpr(KIND == 14) a[i] = m / a[i];                    // IEEE-correct division
             if constexpr(KIND == 15) a[i] = __builtin_sqrtf(a[i] + m);   // IEEE-correct sqrt (+1 add)
         }
@@ -81,14 +92,16 @@ __global__ __launch_bounds__(256) void probe(float *out, float seed, unsigned us
 template <int KIND>
 void run(const char *name, double flop_per_op, float *d_out) {
     const int blocks = 256 * 8, threads = 256;
+    scalar_bank bank;
+    for(int i = 0; i < 16; i++) bank.v[i] = 0.9999f + 1e-6f * i;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(probe<KIND>, dim3(blocks), dim3(threads), 0, 0, d_out, 1.0f, 12345u);
+    hipLaunchKernelGGL(probe<KIND>, dim3(blocks), dim3(threads), 0, 0, d_out, 1.0f, 12345u, bank);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipEventRecord(e0));
     const int reps = 5;
-    for(int r = 0; r < reps; r++) hipLaunchKernelGGL(probe<KIND>, dim3(blocks), dim3(threads), 0, 0, d_out, 1.0f, 12345u);
+    for(int r = 0; r < reps; r++) hipLaunchKernelGGL(probe<KIND>, dim3(blocks), dim3(threads), 0, 0, d_out, 1.0f, 12345u, bank);
     HIPCHK(hipEventRecord(e1));
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0;
@@ -136,6 +149,13 @@ int main() {
     run<26>("fma_sgpr_op", 2, d_out);
     run<27>("fmac_sgpr_op", 2, d_out);
     run<28>("max3", 0, d_out);
+    run<30>("fma_sgpr_rot", 2, d_out);
+    run<31>("fmac_sgpr_rot", 2, d_out);
+    run<32>("fma_sgpr_x4", 2, d_out);
+    run<33>("fma_sgpr_x2", 2, d_out);
+    run<34>("add_u32_sgpr", 0, d_out);
+    run<35>("mov_from_sgpr", 0, d_out);
+    run<36>("mov_vgpr", 0, d_out);
     run<29>("sub_sgpr_op", 1, d_out);
     run<14>("div_ieee", 1, d_out);
     run<15>("sqrt_ieee", 1, d_out);
