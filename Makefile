@@ -7,7 +7,8 @@ ARCH     ?= gfx950
 # -ffp-contract=off: fusion happens only where the source asks for it (exact vs fast paths)
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude
 HOSTCXX  ?= /opt/rocm/lib/llvm/bin/clang++
-HOSTFLAGS := -std=c++20 -O2 -Wall -Wextra -pedantic -Werror -Iinclude -Iraytracer_amd/host
+# -ffp-contract=off: the software backend evaluates IEEE fp32 in source order, like the reference's build (build.sh:7-31)
+HOSTFLAGS := -std=c++20 -O2 -ffp-contract=off -Wall -Wextra -pedantic -Werror -Iinclude -Iraytracer_amd/host
 
 LIB := raytracer_amd/lib/libhip_raytracer.so
 CLI := raytracer_amd/bin/raytracer_hip

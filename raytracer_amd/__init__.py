@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhip_raytracer.so")
+# RAYTRACER_AMD_LIB: another build of the same library (A/B timing of two builds in one session)
+LIB_PATH = os.environ.get("RAYTRACER_AMD_LIB") or os.path.join(_HERE, "lib", "libhip_raytracer.so")
 
 MAT_NORMAL, MAT_LAMBERT, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2, 3
 FLAG_JITTER, FLAG_FAST, FLAG_COUNT_RAYS, FLAG_NO_REGEN = 1, 2, 4, 8

@@ -264,15 +264,47 @@ struct camera_consts {       // travels as a kernel argument (SGPRs)
     float shade_scale;       // 0.5 / r
     float shade_offset[3];   // 0.5 - 0.5 * oc / r
     uint32_t near_root_only; // camera outside the sphere by more than t_min: a hit is the near root
+    float radius2;           // r*r
 };
 
 // Relative margin of the exact build's conservative miss tests (see screen_sphere below).
 constexpr float kScreenMargin = 3e-5f;
 
+// Where the fast build hands a camera ray to the exact arithmetic.  The reference's quadratic
+// (src/shapes.cpp:15-23) forms its discriminant by cancellation, and the hit distance, hence the
+// normal and the colour, moves by the rounding of that discriminant times M / (2 r sqrt(dd disc)),
+// with disc = h*h - dd c and M = h*h + dd (oc.oc + r*r) for the unnormalised ray (h = draw.oc,
+// dd = draw.draw).  With q = disc dd r*r / (M*M), any arithmetic other than the reference's own lands
+// K / sqrt(q) away from the reference's colour; measured on MI355X over the reference's scene
+// at 512x512 .. 3840x2160, off-axis cameras, far, small and grazing spheres: K <= 2.6e-8 for the
+// primary pass, <= 4.9e-8 for the sampling pass (tools/fast_error_map.py).  Rays with q below this
+// threshold, and rays within the screening margin of tangent, are computed in the reference's
+// operation order instead: K / sqrt(kExactBelowQ) = 6.3e-6, inside the 1e-5 the jitter-free
+// primary-hit comparison allows.  On the reference's view that is a ring about 0.9 % of the sphere's
+// radius wide along the silhouette, 2.2 % of the pixels that hit; seen from far away
+// (distance^2 > 65 r*r or so) every hit has q below the threshold.
+constexpr float kExactBelowQ = 6e-5f;
+
 // ------------------------------------------------------------------------------------------
 // primary pass: the reference's pixel kernel, 4 horizontally adjacent pixels per lane so the
 // packed image leaves as one 16-byte store per lane (1 KiB per wave instruction)
 // ------------------------------------------------------------------------------------------
+
+// the reference's pixel, operation for operation: src/ray.h:18-20, src/shapes.cpp:14-30,
+// src/software_raytracer.cpp:226-236
+__device__ __forceinline__ f3 primary_pixel_reference(const f3 cam, const f3 oc, const f3 ctr, float c, const f3 draw, const f3 bg) {
+    const f3 d = normalize3<true>(draw);                        // src/ray.h:18-20
+    // src/shapes.cpp:14-20
+    const float a = dot3<true>(d, d);
+    const float b = -2.0f * dot3<true>(d, oc);
+    const float disc = b * b - (4.0f * a) * c;
+    if(!(disc >= 0.0f)) return bg;
+    // src/shapes.cpp:23-25 : nearest root, no range test
+    const float t = (-b - rt_sqrt<true>(disc)) / (2.0f * a);
+    const f3 p = {d.x * t + cam.x, d.y * t + cam.y, d.z * t + cam.z};
+    const f3 n = normalize3<true>(f3{p.x - ctr.x, p.y - ctr.y, p.z - ctr.z});
+    return f3{remap_unit(n.x), remap_unit(n.y), remap_unit(n.z)};
+}
 
 template <bool EXACT>
 __device__ __forceinline__ f3 primary_pixel(const view_consts &vc, const camera_consts &cc, uint32_t x, uint32_t y, const f3 bg) {
@@ -287,28 +319,25 @@ __device__ __forceinline__ f3 primary_pixel(const view_consts &vc, const camera_
     const float h = __builtin_fmaf(draw.z, oc.z, __builtin_fmaf(draw.y, oc.y, draw.x * oc.x));
     const float q = h * h;
 
-    if constexpr(EXACT) {
-        // Conservative miss test on the unnormalised ray (fused arithmetic): a quarter of the
-        // reference's discriminant has the sign of h*h - dd*c, and either evaluation is within
-        // about a dozen unit roundoffs of h*h + dd*(oc.oc + r*r); below -kScreenMargin of that
-        // magnitude the exact discriminant is negative too and the pixel is background.
-        const float screen = __builtin_fmaf(kScreenMargin, __builtin_fmaf(dd, cc.magnitude, q), __builtin_fmaf(-dd, cc.c, q));
-        if(!(screen >= 0.0f)) return bg;
+    // Conservative miss test on the unnormalised ray (fused arithmetic): a quarter of the
+    // reference's discriminant has the sign of h*h - dd*c, and either evaluation is within
+    // about a dozen unit roundoffs of M = h*h + dd*(oc.oc + r*r); below -kScreenMargin of that
+    // magnitude the exact discriminant is negative too and the pixel is background.
+    const float big = __builtin_fmaf(dd, cc.magnitude, q);
+    const float disc = __builtin_fmaf(-dd, cc.c, q);                // unnormalised ray: t runs along `draw`
+    if(!(__builtin_fmaf(kScreenMargin, big, disc) >= 0.0f)) return bg;
 
-        const f3 d = normalize3<true>(draw);                        // src/ray.h:18-20
-        // src/shapes.cpp:14-20
-        const float a = dot3<true>(d, d);
-        const float b = -2.0f * dot3<true>(d, oc);
-        const float disc = b * b - (4.0f * a) * cc.c;
-        if(!(disc >= 0.0f)) return bg;
-        // src/shapes.cpp:23-25 : nearest root, no range test
-        const float t = (-b - rt_sqrt<true>(disc)) / (2.0f * a);
-        const f3 p = {d.x * t + cam.x, d.y * t + cam.y, d.z * t + cam.z};
-        const f3 n = normalize3<true>(f3{p.x - ctr.x, p.y - ctr.y, p.z - ctr.z});
-        return f3{remap_unit(n.x), remap_unit(n.y), remap_unit(n.z)};
+    if constexpr(EXACT) {
+        return primary_pixel_reference(cam, oc, ctr, cc.c, draw, bg);
     } else {
-        const float disc = __builtin_fmaf(-dd, cc.c, q);            // unnormalised ray: t runs along `draw`
-        if(!(disc >= 0.0f)) return bg;
+        // ill-conditioned hits (see kExactBelowQ) and rays within the margin of tangent take the
+        // reference's arithmetic, ray included (the fast build's ray above is rounded once per
+        // coordinate where the reference rounds twice)
+        if(!(disc * (dd * cc.radius2) >= kExactBelowQ * (big * big))) {
+            const float ex = (static_cast<float>(x) + 0.5f) * vc.psx - vc.vw_half;
+            const float ey = (static_cast<float>(y) + 0.5f) * vc.psy - vc.vh_half;
+            return primary_pixel_reference(cam, oc, ctr, cc.c, f3{ex - cam.x, ey - cam.y, 0.0f - cam.z}, bg);
+        }
         const float t = (h - __builtin_amdgcn_sqrtf(disc)) * __builtin_amdgcn_rcpf(dd);
         const f3 v = {__builtin_fmaf(draw.x, t, cam.x - ctr.x), __builtin_fmaf(draw.y, t, cam.y - ctr.y),
                       __builtin_fmaf(draw.z, t, cam.z - ctr.z)};
@@ -1282,6 +1311,72 @@ __global__ __launch_bounds__(kBlock) void resolve_block_kernel(view_consts vc, c
 }
 
 // ------------------------------------------------------------------------------------------
+// Pixels of the single-sphere camera pass that the fast build must not render with its own
+// arithmetic: those in which some sample position gives a ray within the screening margin of
+// tangent, or a hit with conditioning value q below kExactBelowQ.  Decided per pixel from bounds
+// over the pixel's whole jitter range, so the decision holds for every sample.  Set-up lists
+// them (ring_pixels_kernel; entries x | band row << 16, sorted by the host); the fast build's
+// launch renders the listed pixels with the exact build's code and leaves them out of its own.
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ bool pixel_needs_reference(const view_consts &vc, const camera_consts &cc, uint32_t x, uint32_t y) {
+    const bool jitter = (vc.flags & AEHIP_FLAG_JITTER) != 0;
+    // the sample positions of the pixel span [u0, u0 + eu] x [v0, v0 + ev] on the viewport,
+    // measured from the camera (a single point without jitter)
+    const float xb = static_cast<float>(x) + (jitter ? 0.0f : 0.5f), yb = static_cast<float>(y) + (jitter ? 0.0f : 0.5f);
+    const float u0 = __builtin_fmaf(xb, vc.psx, -(vc.vw_half + vc.cam[0]));
+    const float v0 = __builtin_fmaf(yb, vc.psy, -(vc.vh_half + vc.cam[1]));
+    const float eu = jitter ? vc.psx : 0.0f, ev = jitter ? vc.psy : 0.0f;
+    const float dz = 0.0f - vc.cam[2];
+    float disc_min = 3.402823466e+38f, disc_max = -3.402823466e+38f, big_max = 0.0f;
+#pragma unroll
+    for(int k = 0; k < 4; k++) {
+        const float u = u0 + ((k & 1) ? eu : 0.0f), v = v0 + ((k & 2) ? ev : 0.0f);
+        const float dd = __builtin_fmaf(v, v, __builtin_fmaf(u, u, dz * dz));
+        const float h = __builtin_fmaf(v, cc.oc[1], __builtin_fmaf(u, cc.oc[0], dz * cc.oc[2]));
+        const float disc = __builtin_fmaf(-dd, cc.c, h * h);
+        disc_min = fminf(disc_min, disc);
+        disc_max = fmaxf(disc_max, disc);
+        big_max = fmaxf(big_max, __builtin_fmaf(dd, cc.magnitude, h * h));
+    }
+    // smallest dd over the rectangle: each coordinate at its smallest magnitude
+    const float ua = (u0 <= 0.0f && u0 + eu >= 0.0f) ? 0.0f : fminf(fabsf(u0), fabsf(u0 + eu));
+    const float va = (v0 <= 0.0f && v0 + ev >= 0.0f) ? 0.0f : fminf(fabsf(v0), fabsf(v0 + ev));
+    const float dd_min = __builtin_fmaf(va, va, __builtin_fmaf(ua, ua, dz * dz));
+    // the discriminant is a quadratic in (u, v): inside the rectangle it leaves the range of
+    // the corner values by at most its second-order terms; plus the evaluations' own rounding
+    const float pad = fabsf(cc.q_uu) * eu * eu + fabsf(cc.q_uv) * eu * ev + fabsf(cc.q_vv) * ev * ev + 1e-5f * big_max;
+    const bool may_hit = disc_max + pad >= -(kScreenMargin * 1.01f) * big_max;
+    // q >= kExactBelowQ for every sample of the pixel, with 5 % to spare; false for NaN / inf: such pixels are listed
+    const bool well_conditioned = (disc_min - pad) * (dd_min * cc.radius2) >= (kExactBelowQ * 1.05f) * (big_max * big_max);
+    return may_hit && !well_conditioned;
+}
+
+__global__ __launch_bounds__(256) void ring_pixels_kernel(view_consts vc, camera_consts cc, uint32_t *__restrict__ count,
+                                                          uint32_t *__restrict__ list, uint32_t capacity) {
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    bool ring = false;
+    uint32_t x = 0, row = 0;
+    if(gid < vc.width * vc.row_count) {
+        row = gid / vc.width;
+        x = gid - row * vc.width;
+        ring = pixel_needs_reference(vc, cc, x, image_row(vc, row));
+    }
+    // one atomic per wave
+    const unsigned long long mask = __ballot(ring);
+    if(mask != 0ull) {
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t base = 0;
+        if(lane == static_cast<uint32_t>(__builtin_ctzll(mask))) base = atomicAdd(count, static_cast<uint32_t>(__builtin_popcountll(mask)));
+        base = __shfl(base, __builtin_ctzll(mask), 64);
+        if(ring) {
+            const uint32_t slot = base + static_cast<uint32_t>(__builtin_popcountll(mask & ((1ull << lane) - 1ull)));
+            if(list && slot < capacity) list[slot] = x | (row << 16);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // camera pass: the path pass specialised for scenes in which every surface ends the path
 // (all materials NORMAL -- the reference's scene).  Every path is one segment from the camera,
 // so the sample loop is wave-uniform, the per-sphere terms that only depend on the ray origin
@@ -1299,11 +1394,17 @@ __global__ __launch_bounds__(kBlock) void resolve_block_kernel(view_consts vc, c
 // per wave and adds them once at the end.
 // ------------------------------------------------------------------------------------------
 
-template <bool EXACT, bool ONE, bool FOLD, bool AXIAL>
-__global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_consts cc, uint32_t split_log2,
-                                                        const float4 *__restrict__ geom,
-                                                        const uint32_t *__restrict__ sample_terms,
-                                                        uint32_t *__restrict__ argb, float4 *__restrict__ rgba) {
+//
+// Pixel list: with `pixel_list` a workgroup renders listed pixels (x | band row << 16) instead of
+// a rectangle, 64 consecutive entries taking a strip's place, group_x counting the groups.
+// SKIP_LISTED: pixels that pixel_needs_reference() are left out (the same launch renders them
+// from the list with the exact build's arithmetic, see camera_hybrid_kernel).
+template <bool EXACT, bool ONE, bool FOLD, bool AXIAL, bool SKIP_LISTED>
+__device__ __forceinline__ void camera_body(const view_consts &vc, const camera_consts &cc, uint32_t split_log2,
+                                            const float4 *__restrict__ geom, const uint32_t *__restrict__ sample_terms,
+                                            uint32_t *__restrict__ argb, float4 *__restrict__ rgba, uint32_t group_x,
+                                            uint32_t group_y, const uint32_t *__restrict__ pixel_list, uint32_t list_count,
+                                            uint32_t list_row_bias) {
     constexpr uint32_t kWaves = kBlock / 64;
     __shared__ float4 s_occ[ONE ? 1 : kLdsSpheres];     // oc.xyz, c
     __shared__ float4 s_ctr[ONE ? 1 : kLdsSpheres];     // centre.xyz, oc.oc + r*r
@@ -1315,10 +1416,18 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
     const uint32_t split = 1u << split_log2;                    // waves per strip
     const uint32_t strip = wave >> split_log2;                  // strip of the workgroup
     const uint32_t part = wave & (split - 1u);                  // this wave's place among the strip's waves
-    const uint32_t x = blockIdx.x * kTileW + (lane & 15u);
-    const uint32_t row = (blockIdx.y * (kWaves >> split_log2) + strip) * 4u + (lane >> 4);
+    uint32_t x = group_x * kTileW + (lane & 15u);
+    uint32_t row = (group_y * (kWaves >> split_log2) + strip) * 4u + (lane >> 4);
+    bool valid = (x < vc.width) && (row < vc.row_count);
+    if(pixel_list) {
+        const uint32_t entry = (group_x * (kWaves >> split_log2) + strip) * 64u + lane;
+        valid = entry < list_count;
+        const uint32_t packed = valid ? pixel_list[entry] : 0u;
+        x = packed & 0xffffu;
+        row = (packed >> 16) - list_row_bias;      // entries hold rows of the whole band; a launch may render part of it
+    }
     const uint32_t y = image_row(vc, row);
-    const bool valid = (x < vc.width) && (row < vc.row_count);
+    if constexpr(SKIP_LISTED) valid = valid && !pixel_needs_reference(vc, cc, x, y);
     const f3 cam = {vc.cam[0], vc.cam[1], vc.cam[2]};
     const uint32_t n_spheres = ONE ? 1u : vc.n_spheres;
     const uint32_t nblocks = (vc.spp + AEHIP_SAMPLE_BLOCK - 1u) / AEHIP_SAMPLE_BLOCK;
@@ -1465,6 +1574,9 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
                                     float t = (-b - sq) / a2;
                                     bool ok = (t > kTMin) && (t < closest);
                                     if(!ok) {
+                                        // rare (camera inside a sphere): keep it a branch -- computed
+                                        // unconditionally, the second IEEE division costs every hit 13 issue slots
+                                        asm volatile("");
                                         t = (-b + sq) / a2;
                                         ok = (t > kTMin) && (t < closest);
                                     }
@@ -1649,6 +1761,35 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
     // every lane of a strip busy for each of its samples -- and are filled in by the host.)
 }
 
+template <bool EXACT, bool ONE, bool FOLD, bool AXIAL>
+__global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_consts cc, uint32_t split_log2,
+                                                        const float4 *__restrict__ geom,
+                                                        const uint32_t *__restrict__ sample_terms,
+                                                        uint32_t *__restrict__ argb, float4 *__restrict__ rgba) {
+    camera_body<EXACT, ONE, FOLD, AXIAL, false>(vc, cc, split_log2, geom, sample_terms, argb, rgba, blockIdx.x, blockIdx.y, nullptr, 0u, 0u);
+}
+
+// The fast build's single-sphere launch when the band has ill-conditioned pixels: the first
+// list_groups workgroups render the listed pixels in the reference's arithmetic (the exact
+// build's code, bit for bit its results), the others the rectangle in the fast arithmetic minus
+// those pixels.  One launch, so the few hundred list workgroups run beside the bulk instead of
+// on an empty chip (as a launch of their own they took 0.3 ms of a 2.2 ms 4K frame).
+template <bool FOLD, bool AXIAL>
+__global__ __launch_bounds__(kBlock) void camera_hybrid_kernel(view_consts vc, camera_consts cc, uint32_t split_log2,
+                                                               const uint32_t *__restrict__ sample_terms,
+                                                               uint32_t *__restrict__ argb, float4 *__restrict__ rgba,
+                                                               const uint32_t *__restrict__ pixel_list, uint32_t list_count,
+                                                               uint32_t list_row_bias, uint32_t list_groups, uint32_t groups_x) {
+    if(blockIdx.x < list_groups) {
+        camera_body<true, true, FOLD, AXIAL, false>(vc, cc, split_log2, nullptr, sample_terms, argb, rgba, blockIdx.x, 0u, pixel_list,
+                                                    list_count, list_row_bias);
+    } else {
+        const uint32_t id = blockIdx.x - list_groups;
+        const uint32_t gy = id / groups_x;
+        camera_body<false, true, false, AXIAL, true>(vc, cc, split_log2, nullptr, sample_terms, argb, rgba, id - gy * groups_x, gy, nullptr, 0u, 0u);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side: error reporting, backend object, C ABI
 // ------------------------------------------------------------------------------------------
@@ -1702,6 +1843,9 @@ struct aehip_backend {
     unsigned long long *d_rays = nullptr;    // ray segments, lane slots, strip queue of the streamed pass
     uint32_t *d_sample_terms = nullptr;      // spp + 1 words: per-sample key terms (+1 spare for prefetch)
     uint32_t sample_terms_capacity = 0;
+    uint32_t *d_ring = nullptr;              // fast single-sphere camera pass: pixels the exact kernel redoes, sorted by band row
+    uint32_t ring_capacity = 0, ring_count = 0;
+    std::vector<uint32_t> ring_row_offset;   // entries before band row r (size rows + 1)
     radiance3 *d_radiance = nullptr;         // streamed pass: one block of per-path radiance
     radiance3 *d_totals = nullptr;           //   and the per-pixel sums of finished blocks
     size_t radiance_capacity = 0, totals_capacity = 0;   // in elements
@@ -1729,6 +1873,48 @@ bool takes_streamed_pass(const aehip_backend *b) {
     // (Paths of one segment all end together: nothing to stream, the per-lane pass is leaner.)
     return b->params.list_source != 1u && !(vc.flags & AEHIP_FLAG_NO_REGEN) && vc.n_spheres >= kPoolMinSpheres &&
            vc.max_depth > 1 && b->d_radiance != nullptr;
+}
+
+// Does the camera pass run its single-sphere variant (sphere constants in scalar registers, hits
+// shaded through 1/r) for this backend's scene?  A sphere of (nearly) no radius has no usable
+// 1/r and goes through the list variant.
+bool single_sphere_camera_pass(const aehip_backend *b) {
+    return b->all_terminal && b->vc.n_spheres == 1 && std::isfinite(b->cc.shade_scale) && b->cc.shade_scale < 1e18f;
+}
+
+// Lists the band's ill-conditioned pixels (ring_pixels_kernel): count, size the list, fill, sort
+// by row on the host so that a launch over part of the band takes a contiguous piece of it.
+int build_ring_list(aehip_backend *b) {
+    const view_consts &vc = b->vc;
+    const uint64_t pixels = static_cast<uint64_t>(vc.width) * vc.row_count;
+    const dim3 grid(static_cast<uint32_t>((pixels + 255u) / 256u));
+    uint32_t *d_count = reinterpret_cast<uint32_t *>(b->d_rays + 2);          // the streamed pass's queue word: idle during set-up
+    uint32_t count = 0;
+    AEHIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t), b->stream));
+    hipLaunchKernelGGL(ring_pixels_kernel, grid, dim3(256), 0, b->stream, vc, b->cc, d_count, static_cast<uint32_t *>(nullptr), 0u);
+    AEHIP_CHECK(hipMemcpyAsync(&count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    AEHIP_CHECK(hipStreamSynchronize(b->stream));
+    b->ring_row_offset.assign(static_cast<size_t>(vc.row_count) + 1, 0u);
+    if(count == 0) return AEHIP_OK;
+    if(count > b->ring_capacity) {
+        if(b->d_ring) (void)hipFree(b->d_ring);
+        b->d_ring = nullptr; b->ring_capacity = 0;
+        AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_ring), sizeof(uint32_t) * count));
+        b->ring_capacity = count;
+    }
+    AEHIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t), b->stream));
+    hipLaunchKernelGGL(ring_pixels_kernel, grid, dim3(256), 0, b->stream, vc, b->cc, d_count, b->d_ring, count);
+    std::vector<uint32_t> list(count);
+    AEHIP_CHECK(hipMemcpyAsync(list.data(), b->d_ring, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, b->stream));
+    AEHIP_CHECK(hipStreamSynchronize(b->stream));
+    // row-major order (the row is the high half of an entry)
+    std::sort(list.begin(), list.end());
+    for(uint32_t e : list) b->ring_row_offset[static_cast<size_t>(e >> 16) + 1]++;
+    for(size_t r = 0; r < vc.row_count; r++) b->ring_row_offset[r + 1] += b->ring_row_offset[r];
+    AEHIP_CHECK(hipMemcpyAsync(b->d_ring, list.data(), sizeof(uint32_t) * count, hipMemcpyHostToDevice, b->stream));
+    AEHIP_CHECK(hipStreamSynchronize(b->stream));
+    b->ring_count = count;
+    return AEHIP_OK;
 }
 
 int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t stream) {
@@ -1762,7 +1948,7 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         const uint32_t rows_per_group = static_cast<uint32_t>(kTileH) >> split_log2;
         const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + rows_per_group - 1) / rows_per_group);
         // a sphere of (nearly) no radius has no usable 1/r: it goes through the list variant
-        const bool one = vc.n_spheres == 1 && std::isfinite(b->cc.shade_scale) && b->cc.shade_scale < 1e18f;
+        const bool one = single_sphere_camera_pass(b);
         const bool fold = (vc.flags & kFlagFoldScreen) != 0;
 #define AEHIP_LAUNCH_CAMERA(E, O, F, A)                                                                                \
     do {                                                                                                               \
@@ -1783,7 +1969,19 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
             else if(fold) AEHIP_LAUNCH_CAMERA(true, false, true, false);
             else AEHIP_LAUNCH_CAMERA(true, false, false, false);
         } else {
-            if(one && axial) AEHIP_LAUNCH_CAMERA(false, true, false, true);
+            if(one && b->ring_count > 0) {
+                // the band has ill-conditioned pixels: those of this launch's rows come first in the
+                // grid, from the list, in the reference's arithmetic
+                const uint32_t row0 = vc.tile_rows == 0 ? vc.row_begin - b->params.row_begin : 0u;
+                const uint32_t first = b->ring_row_offset[row0], last = b->ring_row_offset[row0 + vc.row_count];
+                const uint32_t per_group = 64u * (static_cast<uint32_t>(kBlock / 64) >> split_log2);
+                const uint32_t list_groups = (last - first + per_group - 1u) / per_group;
+                const dim3 line(list_groups + grid.x * grid.y);
+                if(fold && axial) { func = reinterpret_cast<const void *>(camera_hybrid_kernel<true, true>); hipLaunchKernelGGL((camera_hybrid_kernel<true, true>), line, dim3(kBlock), 0, stream, vc, b->cc, split_log2, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, grid.x); }
+                else if(fold) { func = reinterpret_cast<const void *>(camera_hybrid_kernel<true, false>); hipLaunchKernelGGL((camera_hybrid_kernel<true, false>), line, dim3(kBlock), 0, stream, vc, b->cc, split_log2, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, grid.x); }
+                else { func = reinterpret_cast<const void *>(camera_hybrid_kernel<false, false>); hipLaunchKernelGGL((camera_hybrid_kernel<false, false>), line, dim3(kBlock), 0, stream, vc, b->cc, split_log2, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, grid.x); }
+            }
+            else if(one && axial) AEHIP_LAUNCH_CAMERA(false, true, false, true);
             else if(one) AEHIP_LAUNCH_CAMERA(false, true, false, false);
             else AEHIP_LAUNCH_CAMERA(false, false, false, false);
         }
@@ -1945,6 +2143,9 @@ void aehip_backend_destroy(aehip_backend *b) {
     if(b->d_geom) (void)hipFree(b->d_geom);
     if(b->d_matl) (void)hipFree(b->d_matl);
     if(b->d_kind) (void)hipFree(b->d_kind);
+    if(b->d_camera) (void)hipFree(b->d_camera);
+    if(b->d_prefilter) (void)hipFree(b->d_prefilter);
+    if(b->d_ring) (void)hipFree(b->d_ring);
     if(b->d_argb) (void)hipFree(b->d_argb);
     if(b->d_rays) (void)hipFree(b->d_rays);
     if(b->d_sample_terms) (void)hipFree(b->d_sample_terms);
@@ -2143,6 +2344,7 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
             b->cc.shade_offset[1] = static_cast<float>(0.5 - 0.5 * ky / r0);
             b->cc.shade_offset[2] = static_cast<float>(0.5 - 0.5 * static_cast<double>(ocz) / r0);
             b->cc.near_root_only = std::sqrt(static_cast<double>(occ)) - r0 > 1.001 * static_cast<double>(kTMin) ? 1u : 0u;
+            b->cc.radius2 = geom[0].w;
         }
         hipError_t e = hipMemcpyAsync(b->d_geom, geom, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
         if(e == hipSuccess) e = hipMemcpyAsync(b->d_matl, matl, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
@@ -2189,6 +2391,14 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
                 }
             }
         }
+    }
+
+    // fast build, single-sphere camera pass: the pixels the exact kernel renders (ring_pixels_kernel)
+    b->ring_count = 0;
+    b->ring_row_offset.clear();
+    if((p.flags & AEHIP_FLAG_FAST) && p.pass == AEHIP_PASS_PATH && single_sphere_camera_pass(b)) {
+        const int rc = build_ring_list(b);
+        if(rc != AEHIP_OK) return rc;
     }
 
     // per-sample key terms

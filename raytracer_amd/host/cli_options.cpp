@@ -29,7 +29,8 @@ const flag_spec specs[] = {
     {"--height", "height", kind::number, 512u},
     {"--compute", "compute", kind::toggle, false},
     {"--output", "output", kind::text, std::monostate{}},
-    // HIP backend
+    // backend choice: --hip selects the MI355X backend as --compute selects the reference's Vulkan one
+    // (src/main.cpp:40-42); without it, or when it cannot start, the software backend renders
     {"--hip", "hip", kind::toggle, false},
     {"--gpus", "gpus", kind::number, 1u},
     {"--spp", "spp", kind::number, 1u},
@@ -40,6 +41,7 @@ const flag_spec specs[] = {
     {"--fast", "fast", kind::toggle, false},
     {"--stats", "stats", kind::toggle, false},
     {"--tight-file", "tight-file", kind::toggle, false},
+    {"--threads", "threads", kind::number, 0u},      // software backend: worker threads, 0 = one per processor
 };
 constexpr size_t spec_count = sizeof(specs) / sizeof(specs[0]);
 

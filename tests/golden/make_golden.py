@@ -103,9 +103,14 @@ def main():
             with open(os.path.join(td, "output.tga"), "rb") as f:
                 header = f.read(18)
             size = os.path.getsize(os.path.join(td, "output.tga"))
-        cli.append({"args": args, "width": int.from_bytes(header[12:14], "little"),
-                    "height": int.from_bytes(header[14:16], "little"), "header_hex": header.hex(), "file_size": size})
-        print("cli", args, cli[-1]["width"], cli[-1]["height"], size)
+        cw, ch = int.from_bytes(header[12:14], "little"), int.from_bytes(header[14:16], "little")
+        # the image the reference's pixel kernel gives at that size (single-threaded probe: at
+        # tiny sizes the reference's scheduler sometimes returns before its last tiles are copied)
+        pw, ph, img = run_probe("image", cw, ch)
+        assert (pw, ph) == (cw, ch)
+        cli.append({"args": args, "width": cw, "height": ch, "header_hex": header.hex(), "file_size": size,
+                    "payload_sha256": hashlib.sha256(img.tobytes()).hexdigest()})
+        print("cli", args, cw, ch, size)
     with open(os.path.join(HERE, "reference_cli.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden.py", "cases": cli}, f, indent=1)
 

@@ -5,10 +5,10 @@
 
 Bars: the exact build (default) is bit-identical: every packed 0xAARRGGBB word and every
 pre-quantisation float (error 0, inside the 1e-5 the jitter-free primary-hit comparison allows).
-The fast build (AEHIP_FLAG_FAST: fused multiply-add, hardware reciprocal / rsqrt) is held to
-|colour difference| <= 1e-5 per channel except on at most 0.15*(W+H) silhouette pixels (<= 5e-4
-anywhere), to
-<= 1 code value on at most 0.2 % of packed pixels, and to PSNR bounds on path-traced images.
+The fast build (AEHIP_FLAG_FAST: fused multiply-add, hardware reciprocal / rsqrt; rays too
+ill-conditioned for that are computed in the reference's operation order) is held to
+|colour difference| <= 1e-5 per channel on every pixel of jitter-free primary-hit renders, to
+<= 1 code value on at most 0.1 % of packed pixels, and to PSNR bounds on path-traced images.
 """
 import hashlib
 import json
@@ -179,47 +179,67 @@ def test_seed_changes_the_image_and_same_seed_repeats_it():
 
 # ------------------------------------------------------------------ fast build: stated tolerances
 
-@pytest.mark.parametrize("size", [(512, 512), (1920, 1080), (3840, 2160)])
+@pytest.mark.parametrize("size", [(512, 512), (1920, 1080), (3840, 2160), (1004, 4), (100, 200)])
 def test_fast_primary_within_1e5_of_reference_floats(size):
+    """The jitter-free primary-hit render of the fast build against the reference's floats (= the
+    exact build's, see test_primary_pass_floats_match_reference_records): at most 1e-5 per channel
+    on EVERY pixel.  The fast arithmetic alone cannot give that near the silhouette -- the
+    reference's quadratic amplifies any rounding difference where its discriminant cancels -- so
+    the fast kernels compute ill-conditioned rays (conditioning value below kExactBelowQ, or
+    within the screening margin of tangent) in the reference's own operation order."""
     w, h = size
     _, exact_rgba, _ = render_device(w, h, pass_=rt.PASS_PRIMARY)
     fast_argb, fast_rgba, _ = render_device(w, h, pass_=rt.PASS_PRIMARY, fast=True)
-    # The exact build is the one that meets "within 1e-5 of the reference" (its error is 0, see
-    # test_primary_pass_floats_match_reference_records).  The fast build rounds differently, and
-    # the reference's quadratic amplifies any rounding difference where the discriminant is
-    # close to 0 (grazing rays on the silhouette, a curve whose length grows with W+H), so its
-    # bound is stated on the distribution: within 1e-5 everywhere except on at most 0.15*(W+H)
-    # silhouette pixels (0.06 % of a 512x512 image, 0.01 % of a 4K one), never further than 5e-4.
     err = np.abs(fast_rgba[..., :3] - exact_rgba[..., :3]).max(axis=-1)
-    assert float(err.max()) <= 5e-4
-    assert np.count_nonzero(err > 1e-5) <= 0.15 * (w + h)
+    assert float(err.max()) <= 1e-5
     want = next(e["sha256"] for e in META["images"] if (e["width"], e["height"]) == (w, h))
     exact_argb, _ = rt.render(w, h, pass_=rt.PASS_PRIMARY)
     assert sha(exact_argb) == want
+    # packed words: the reference truncates, so a float difference of one rounding flips a code
+    # value wherever colour*255 sits on an integer: never more than one, on few pixels
     diff = np.abs(channels(fast_argb) - channels(exact_argb))
-    assert diff.max() <= 1                                               # never more than one code value
-    assert np.count_nonzero(diff.max(axis=-1)) <= 0.002 * w * h          # on at most 0.2 % of pixels
+    assert diff.max() <= 1
+    assert np.count_nonzero(diff.max(axis=-1)) <= max(2, 0.001 * w * h)
 
 
-@pytest.mark.parametrize("size", [(512, 512), (1920, 1080), (3840, 2160)])
+@pytest.mark.parametrize("size", [(512, 512), (1920, 1080), (3840, 2160), (1004, 4), (100, 200)])
 @pytest.mark.parametrize("spp", [1, 4])
 def test_fast_sampling_kernel_jitter_free_within_1e5_of_reference_floats(size, spp):
     """The same bound through the spp/depth kernel (per-pixel quadratic hit test, normal from the
     hit point over the radius): jitter-free samples all sit at the pixel centre, so the mean of
-    a power-of-two number of them is the reference's pixel (sums and the division are exact)."""
+    a power-of-two number of them is the reference's pixel (sums and the division are exact).
+    Pixels with an ill-conditioned ray are rendered a second time by the exact build's kernel
+    (pixel list built at set-up), so no sample lands on the other side of the hit test either."""
     w, h = size
     _, exact_rgba, _ = render_device(w, h, pass_=rt.PASS_PRIMARY)           # = the reference's floats
     fast_argb, fast_rgba, _ = render_device(w, h, pass_=rt.PASS_PATH, spp=spp, max_depth=8, fast=True)
     err = np.abs(fast_rgba[..., :3] - exact_rgba[..., :3]).max(axis=-1)
-    assert np.count_nonzero(err > 1e-5) <= 0.15 * (w + h)
-    # A ray within rounding of tangent can land on the other side of the hit test in any
-    # arithmetic but the reference's own; such a pixel changes by the whole difference between
-    # sphere and background.  Measured: none up to 2560x1440, one mirrored pair at 3840x2160.
-    assert np.count_nonzero(err > 5e-4) <= 4
+    assert float(err.max()) <= 1e-5
     exact_argb, _ = rt.render(w, h, pass_=rt.PASS_PRIMARY)
     diff = np.abs(channels(fast_argb) - channels(exact_argb)).max(axis=-1)
-    assert np.count_nonzero(diff > 1) <= 4
-    assert np.count_nonzero(diff) <= 0.002 * w * h
+    assert diff.max() <= 1
+    assert np.count_nonzero(diff) <= max(2, 0.001 * w * h)
+
+
+@pytest.mark.parametrize("view", ["far_small", "very_far", "large_near", "off_axis_camera", "grazing"])
+def test_fast_build_within_1e5_of_exact_on_other_single_sphere_views(view):
+    """Jitter-free, one sphere, other geometry than the reference's: far and small spheres (every
+    hit ill-conditioned: the whole sphere goes through the reference's arithmetic), a sphere that
+    fills the view, a camera off the sphere's axis, a silhouette through the image centre.  Both
+    fast kernels stay within 1e-5 of the exact build on every pixel."""
+    center, radius, cam = {"far_small": ((0.3, 0.1, -6.0), 0.5, (0.0, 0.0, 1.0)), "very_far": ((0.0, 0.0, -20.0), 1.0, (0.0, 0.0, 1.0)),
+                           "large_near": ((0.5, -0.2, -3.0), 2.5, (0.0, 0.0, 1.0)), "off_axis_camera": ((0.0, 0.0, -2.0), 1.0, (0.6, 0.3, 1.4)),
+                           "grazing": ((1.0, 0.0, -2.0), 1.0, (0.0, 0.0, 1.0))}[view]
+    s = np.zeros(1, dtype=rt.SPHERE_DTYPE)
+    s["center"][0] = center
+    s["radius"] = radius
+    s["material"] = rt.MAT_NORMAL
+    w, h = 1024, 576
+    for pass_ in (rt.PASS_PRIMARY, rt.PASS_PATH):
+        _, exact_rgba, _ = render_device(w, h, pass_=pass_, spheres=s, cam=cam)
+        _, fast_rgba, _ = render_device(w, h, pass_=pass_, spheres=s, cam=cam, fast=True)
+        err = np.abs(fast_rgba[..., :3] - exact_rgba[..., :3]).max(axis=-1)
+        assert float(err.max()) <= 1e-5, (view, pass_)
 
 
 def test_fast_path_pass_converges_to_the_oracle_image():

@@ -35,7 +35,7 @@ def main():
         out.append("== per-dispatch resources of the renderer's kernels ==")
         rows = q(trace, "select name,grid_x,grid_y,workgroup_x,vgpr_count,accum_vgpr_count,sgpr_count,lds_size,scratch_size,"
                         "min(duration),avg(duration),max(duration),count(*) from kernels "
-                        "where name like '%path_kernel%' or name like '%primary_kernel%' or name like '%camera_kernel%' "
+                        "where name like '%path_kernel%' or name like '%primary_kernel%' or name like '%camera_kernel%' or name like '%camera_hybrid_kernel%' or name like '%ring_pixels_kernel%' "
                         "or name like '%path_stream%' or name like '%first_hit_kernel%' or name like '%resolve_block_kernel%' group by name,grid_x,grid_y")
         for r in rows:
             out.append(f"{r[0][:90]}\n    grid {r[1]}x{r[2]} wg {r[3]} vgpr {r[4]} agpr {r[5]} sgpr {r[6]} lds {r[7]} scratch {r[8]}"
@@ -47,7 +47,7 @@ def main():
             continue
         out.append(f"== rocprofv3 --pmc ({sub}) : per-launch mean over the renderer's kernel launches ==")
         rows = q(db, "select kernel_name,counter_name,avg(value),count(*),avg(duration) from counters_collection "
-                     "where kernel_name like '%path_kernel%' or kernel_name like '%primary_kernel%' or kernel_name like '%camera_kernel%' "
+                     "where kernel_name like '%path_kernel%' or kernel_name like '%primary_kernel%' or kernel_name like '%camera_kernel%' or kernel_name like '%camera_hybrid_kernel%' or kernel_name like '%ring_pixels_kernel%' "
                      "or kernel_name like '%path_stream%' or kernel_name like '%first_hit_kernel%' or kernel_name like '%resolve_block_kernel%' "
                      "group by kernel_name,counter_name")
         for kname, cname, val, n, dur in rows:
