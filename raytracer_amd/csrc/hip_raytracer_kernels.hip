@@ -1399,7 +1399,7 @@ __global__ __launch_bounds__(256) void ring_pixels_kernel(view_consts vc, camera
 // a rectangle, 64 consecutive entries taking a strip's place, group_x counting the groups.
 // SKIP_LISTED: pixels that pixel_needs_reference() are left out (the same launch renders them
 // from the list with the exact build's arithmetic, see camera_hybrid_kernel).
-template <bool EXACT, bool ONE, bool FOLD, bool AXIAL, bool SKIP_LISTED>
+template <bool EXACT, bool ONE, bool FOLD, bool AXIAL, bool SKIP_LISTED, bool FAST_AFTER_DISC = false>
 __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_consts &cc, uint32_t split_log2,
                                             const float4 *__restrict__ geom, const uint32_t *__restrict__ sample_terms,
                                             uint32_t *__restrict__ argb, float4 *__restrict__ rgba, uint32_t group_x,
@@ -1570,14 +1570,19 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                                 const float b = -2.0f * dot3<true>(d, f3{k.x, k.y, k.z});
                                 const float disc = b * b - a4 * k.w;
                                 if(disc >= 0.0f) {
-                                    const float sq = rt_sqrt<true>(disc);
-                                    float t = (-b - sq) / a2;
+                                    // FAST_AFTER_DISC: up to here the sample is the reference's, bit for
+                                    // bit (ray, normalisation, discriminant -- where its rounding is
+                                    // amplified); from here on nothing amplifies, and the hardware's
+                                    // approximate square root and reciprocals are within 1e-6 of it
+                                    const float sq = FAST_AFTER_DISC ? __builtin_amdgcn_sqrtf(disc) : rt_sqrt<true>(disc);
+                                    const float inv_a2 = FAST_AFTER_DISC ? __builtin_amdgcn_rcpf(a2) : 0.0f;
+                                    float t = FAST_AFTER_DISC ? (-b - sq) * inv_a2 : (-b - sq) / a2;
                                     bool ok = (t > kTMin) && (t < closest);
                                     if(!ok) {
                                         // rare (camera inside a sphere): keep it a branch -- computed
                                         // unconditionally, the second IEEE division costs every hit 13 issue slots
                                         asm volatile("");
-                                        t = (-b + sq) / a2;
+                                        t = FAST_AFTER_DISC ? (-b + sq) * inv_a2 : (-b + sq) / a2;
                                         ok = (t > kTMin) && (t < closest);
                                     }
                                     if(ok) {
@@ -1589,9 +1594,16 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                             if(hit >= 0) {
                                 const f3 ctr = ONE ? f3{cc.center[0], cc.center[1], cc.center[2]}
                                                    : f3{s_ctr[hit].x, s_ctr[hit].y, s_ctr[hit].z};
-                                const f3 pt = {d.x * closest + cam.x, d.y * closest + cam.y, d.z * closest + cam.z};
-                                const f3 n = normalize3<true>(f3{pt.x - ctr.x, pt.y - ctr.y, pt.z - ctr.z});
-                                L = f3{remap_unit(n.x), remap_unit(n.y), remap_unit(n.z)};      // throughput is 1
+                                if constexpr(FAST_AFTER_DISC) {
+                                    const f3 v = {__builtin_fmaf(d.x, closest, cam.x - ctr.x), __builtin_fmaf(d.y, closest, cam.y - ctr.y),
+                                                  __builtin_fmaf(d.z, closest, cam.z - ctr.z)};
+                                    const float half_inv = 0.5f * __builtin_amdgcn_rsqf(dot3<false>(v, v));
+                                    L = f3{__builtin_fmaf(v.x, half_inv, 0.5f), __builtin_fmaf(v.y, half_inv, 0.5f), __builtin_fmaf(v.z, half_inv, 0.5f)};
+                                } else {
+                                    const f3 pt = {d.x * closest + cam.x, d.y * closest + cam.y, d.z * closest + cam.z};
+                                    const f3 n = normalize3<true>(f3{pt.x - ctr.x, pt.y - ctr.y, pt.z - ctr.z});
+                                    L = f3{remap_unit(n.x), remap_unit(n.y), remap_unit(n.z)};      // throughput is 1
+                                }
                             }
                         }
                         block.x += L.x;
@@ -1770,19 +1782,22 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
 }
 
 // The fast build's single-sphere launch when the band has ill-conditioned pixels: the first
-// list_groups workgroups render the listed pixels in the reference's arithmetic (the exact
-// build's code, bit for bit its results), the others the rectangle in the fast arithmetic minus
-// those pixels.  One launch, so the few hundred list workgroups run beside the bulk instead of
+// list_groups workgroups render the listed pixels with the exact build's code up to the
+// discriminant (the reference's ray, normalisation and hit decision, bit for bit) and the fast
+// arithmetic after it, the others the rectangle in the fast arithmetic minus those pixels.  One launch, so the few hundred list workgroups run beside the bulk instead of
 // on an empty chip (as a launch of their own they took 0.3 ms of a 2.2 ms 4K frame).
+// (8 waves per SIMD asked for explicitly: the two bodies together would otherwise take 98 scalar
+// registers, one allocation step over what 8 waves leave each other, and the pass lives on its
+// occupancy -- measured 2.19 ms a frame at 7 waves against 2.06 at 8.)
 template <bool FOLD, bool AXIAL>
-__global__ __launch_bounds__(kBlock) void camera_hybrid_kernel(view_consts vc, camera_consts cc, uint32_t split_log2,
+__global__ __launch_bounds__(kBlock, 8) void camera_hybrid_kernel(view_consts vc, camera_consts cc, uint32_t split_log2,
                                                                const uint32_t *__restrict__ sample_terms,
                                                                uint32_t *__restrict__ argb, float4 *__restrict__ rgba,
                                                                const uint32_t *__restrict__ pixel_list, uint32_t list_count,
                                                                uint32_t list_row_bias, uint32_t list_groups, uint32_t groups_x) {
     if(blockIdx.x < list_groups) {
-        camera_body<true, true, FOLD, AXIAL, false>(vc, cc, split_log2, nullptr, sample_terms, argb, rgba, blockIdx.x, 0u, pixel_list,
-                                                    list_count, list_row_bias);
+        camera_body<true, true, FOLD, AXIAL, false, true>(vc, cc, split_log2, nullptr, sample_terms, argb, rgba, blockIdx.x, 0u, pixel_list,
+                                                          list_count, list_row_bias);
     } else {
         const uint32_t id = blockIdx.x - list_groups;
         const uint32_t gy = id / groups_x;

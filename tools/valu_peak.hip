@@ -1,17 +1,22 @@
-// valu_peak: measures what one MI355X sustains for the instruction kinds the renderer is made
-// of, so roofline fractions can be priced against measured ceilings as well as the datasheet's.
-// Every probe is a loop of inline-asm instructions on 16 independent registers (the compiler
-// cannot pack, fuse or fold them), 8 waves per SIMD resident.
-// Prints one line per kind: wave-instructions issued per second per lane and implied TFLOP/s.
+// valu_peak: what one MI355X SIMD sustains for the vector instructions the renderer is made of,
+// in shader clocks per wave-instruction (clock-independent) and as a chip-wide rate at the clock
+// the chip actually held.
+//
+// Method.  The probe loop is one inline-asm block on hard-coded vector registers, so operand
+// banks are controlled (a register's bank is its number mod 4): 16 accumulators v16..v31, second
+// operands v32..v47, third operands v48..v63; instruction i reads v(16+i), v(32+(i+1)%16),
+// v(48+(i+2)%16) -- three different banks -- and the "same bank" variants read v(32+i), v(48+i).
+// 64 instructions per loop iteration, a scalar counter.  Every wave brackets its loop with
+// s_memtime (shader clock) and s_memrealtime (constant-rate clock), so a run yields
+//   sustained shader clock               = d(memtime) / d(memrealtime) * realtime rate
+//   cycles per wave-instruction per SIMD = that clock * SIMDs * 64 / (lane-operations per second)
+// without assuming any clock (the rate is the whole launch's work over its HIP-event time).  The
+// grid is CUs * 4 * W waves, W = 1, 2, 4, 8 per SIMD.  Each measurement runs >= 50 ms.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
 #include <cstdlib>
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-constexpr int kIters = 2048;
-constexpr int kAcc = 16;
+#include <vector>
 
 #define HIPCHK(x)                                                                     \
     do {                                                                              \
@@ -22,143 +27,177 @@ constexpr int kAcc = 16;
         }                                                                             \
     } while(0)
 
-struct scalar_bank {
-    float v[16];
+// one instruction per accumulator, operand registers rotated so the three sources sit in three banks
+#define ROT16(OP)                                                                                                      \
+    OP(16, 33, 50) OP(17, 34, 51) OP(18, 35, 52) OP(19, 36, 53) OP(20, 37, 54) OP(21, 38, 55) OP(22, 39, 56) OP(23, 40, 57) \
+    OP(24, 41, 58) OP(25, 42, 59) OP(26, 43, 60) OP(27, 44, 61) OP(28, 45, 62) OP(29, 46, 63) OP(30, 47, 48) OP(31, 32, 49)
+// all three sources in the accumulator's bank
+#define SAME16(OP)                                                                                                     \
+    OP(16, 32, 48) OP(17, 33, 49) OP(18, 34, 50) OP(19, 35, 51) OP(20, 36, 52) OP(21, 37, 53) OP(22, 38, 54) OP(23, 39, 55) \
+    OP(24, 40, 56) OP(25, 41, 57) OP(26, 42, 58) OP(27, 43, 59) OP(28, 44, 60) OP(29, 45, 61) OP(30, 46, 62) OP(31, 47, 63)
+
+#define I_FMA(a, b, c) "v_fma_f32 v" #a ", v" #a ", v" #b ", v" #c "\n"
+#define I_FMA_S(a, b, c) "v_fma_f32 v" #a ", v" #a ", s22, v" #c "\n"              /* a scalar-register operand */
+#define I_FMAC_S(a, b, c) "v_fmac_f32 v" #a ", s22, v" #c "\n"
+#define I_MUL(a, b, c) "v_mul_f32 v" #a ", v" #a ", v" #b "\n"
+#define I_ADD(a, b, c) "v_add_f32 v" #a ", v" #a ", v" #c "\n"
+#define I_ADD_S(a, b, c) "v_add_f32 v" #a ", s22, v" #a "\n"
+#define I_PKFMA(a, b, c) "v_pk_fma_f32 v[" #a ":" #a "+1], v[" #a ":" #a "+1], v[" #b ":" #b "+1], v[" #c ":" #c "+1]\n"
+#define I_MULLO(a, b, c) "v_mul_lo_u32 v" #a ", v" #a ", v" #b "\n"
+#define I_ADDU(a, b, c) "v_add_u32 v" #a ", v" #a ", v" #b "\n"
+#define I_ADDU_S(a, b, c) "v_add_u32 v" #a ", s22, v" #a "\n"
+#define I_XOR(a, b, c) "v_xor_b32 v" #a ", v" #a ", v" #b "\n"
+#define I_CVT(a, b, c) "v_cvt_f32_u32 v" #a ", v" #b "\n"
+#define I_CVT_SDWA(a, b, c) "v_cvt_f32_u32_sdwa v" #a ", v" #b " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+#define I_CMP(a, b, c) "v_cmp_le_f32 vcc, v" #a ", v" #b "\n"
+#define I_RCP(a, b, c) "v_rcp_f32 v" #a ", v" #b "\n"
+#define I_SQRT(a, b, c) "v_sqrt_f32 v" #a ", v" #b "\n"
+#define I_MAX3(a, b, c) "v_max3_f32 v" #a ", v" #a ", v" #b ", v" #c "\n"
+#define I_MOV_S(a, b, c) "v_mov_b32 v" #a ", s22\n"
+// the fast camera pass's missing sample: key add (scalar operand), two conversions, four fmas, one compare
+#define I_SAMPLE(a, b, c)                                                                                              \
+    "v_add_u32 v" #a ", s22, v" #b "\n"                                                                               \
+    "v_cvt_f32_u32_sdwa v" #b ", v" #a " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"                        \
+    "v_cvt_f32_u32_sdwa v" #c ", v" #a " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n"                        \
+    "v_fma_f32 v0, v" #b ", v1, v2\n"                                                                                  \
+    "v_fma_f32 v3, v" #c ", v4, v5\n"                                                                                  \
+    "v_fma_f32 v3, v" #c ", v3, v6\n"                                                                                  \
+    "v_fma_f32 v0, v" #b ", v0, v3\n"                                                                                  \
+    "v_cmp_le_f32 vcc, 0, v0\n"
+
+// packed instructions use register pairs: 8 pair-accumulators
+#define PAIR8(OP) OP(16, 34, 52) OP(18, 36, 54) OP(20, 38, 56) OP(22, 40, 58) OP(24, 42, 60) OP(26, 44, 62) OP(28, 46, 48) OP(30, 32, 50)
+
+struct stamp {
+    unsigned long long cycles, ticks;
 };
 
-template <int KIND>
-__global__ __launch_bounds__(256) void probe(float *out, float seed, unsigned useed, scalar_bank bank) {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    float a[kAcc];
-    v2f p[kAcc];
-    unsigned u[kAcc];
-#pragma unroll
-    for(int i = 0; i < kAcc; i++) {
-        a[i] = seed + 0.001f * i + 1e-6f * tid;
-        p[i] = v2f{a[i], a[i] * 0.5f};
-        u[i] = useed + i * 2654435761u + tid;
+#define PROBE_KERNEL(NAME, BODY64)                                                                                     \
+    __global__ __launch_bounds__(256) void NAME(stamp *out, int iters, float operand) {                              \
+        unsigned long long t0, t1, r0, r1;                                                                             \
+        asm volatile("v_mov_b32 v0, 1.0\n v_mov_b32 v1, 0x3a83126f\n v_mov_b32 v2, 0.5\n v_mov_b32 v3, 1.0\n"         \
+                     "v_mov_b32 v4, 0x3a83126f\n v_mov_b32 v5, 0.5\n v_mov_b32 v6, -1.0\n" ::: "v0", "v1", "v2", "v3", "v4", "v5", "v6"); \
+        asm volatile(                                                                                                  \
+            "v_mov_b32 v16, 1.0\n v_mov_b32 v17, 1.0\n v_mov_b32 v18, 1.0\n v_mov_b32 v19, 1.0\n"                     \
+            "v_mov_b32 v20, 1.0\n v_mov_b32 v21, 1.0\n v_mov_b32 v22, 1.0\n v_mov_b32 v23, 1.0\n"                     \
+            "v_mov_b32 v24, 1.0\n v_mov_b32 v25, 1.0\n v_mov_b32 v26, 1.0\n v_mov_b32 v27, 1.0\n"                     \
+            "v_mov_b32 v28, 1.0\n v_mov_b32 v29, 1.0\n v_mov_b32 v30, 1.0\n v_mov_b32 v31, 1.0\n"                     \
+            "v_mov_b32 v32, 0x3f7ff972\n v_mov_b32 v33, 0x3f7ff972\n v_mov_b32 v34, 0x3f7ff972\n v_mov_b32 v35, 0x3f7ff972\n" \
+            "v_mov_b32 v36, 0x3f7ff972\n v_mov_b32 v37, 0x3f7ff972\n v_mov_b32 v38, 0x3f7ff972\n v_mov_b32 v39, 0x3f7ff972\n" \
+            "v_mov_b32 v40, 0x3f7ff972\n v_mov_b32 v41, 0x3f7ff972\n v_mov_b32 v42, 0x3f7ff972\n v_mov_b32 v43, 0x3f7ff972\n" \
+            "v_mov_b32 v44, 0x3f7ff972\n v_mov_b32 v45, 0x3f7ff972\n v_mov_b32 v46, 0x3f7ff972\n v_mov_b32 v47, 0x3f7ff972\n" \
+            "v_mov_b32 v48, 0x38d1b717\n v_mov_b32 v49, 0x38d1b717\n v_mov_b32 v50, 0x38d1b717\n v_mov_b32 v51, 0x38d1b717\n" \
+            "v_mov_b32 v52, 0x38d1b717\n v_mov_b32 v53, 0x38d1b717\n v_mov_b32 v54, 0x38d1b717\n v_mov_b32 v55, 0x38d1b717\n" \
+            "v_mov_b32 v56, 0x38d1b717\n v_mov_b32 v57, 0x38d1b717\n v_mov_b32 v58, 0x38d1b717\n v_mov_b32 v59, 0x38d1b717\n" \
+            "v_mov_b32 v60, 0x38d1b717\n v_mov_b32 v61, 0x38d1b717\n v_mov_b32 v62, 0x38d1b717\n v_mov_b32 v63, 0x38d1b717\n" \
+            ::: "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33",   \
+                "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",   \
+                "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");                       \
+        t0 = __builtin_amdgcn_s_memtime();                                                                             \
+        r0 = __builtin_amdgcn_s_memrealtime();                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(t0), "s"(r0));                                                      \
+        asm volatile("s_mov_b32 s20, %0\n s_mov_b32 s22, %1\n"                                                         \
+                     "1:\n" BODY64 "s_sub_u32 s20, s20, 1\n s_cmp_lg_u32 s20, 0\n s_cbranch_scc1 1b\n"                 \
+                     :: "s"(iters), "s"(operand)                                                                       \
+                     : "s20", "s22", "scc", "vcc", "v0", "v3", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", \
+                       "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43",      \
+                       "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",      \
+                       "v60", "v61", "v62", "v63");                                                                    \
+        t1 = __builtin_amdgcn_s_memtime();                                                                             \
+        r1 = __builtin_amdgcn_s_memrealtime();                                                                         \
+        if((threadIdx.x & 63u) == 0u) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = stamp{t1 - t0, r1 - r0};     \
     }
-    float m = 0.9999f + seed * 1e-7f, c = 1e-4f + seed * 1e-8f;
-    v2f pm = {m, m}, pc = {c, c};
-    unsigned um = 747796405u + useed;
-    for(int it = 0; it < kIters; it++) {
-#pragma unroll
-        for(int i = 0; i < kAcc; i++) {
-            if constexpr(KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
-            if constexpr(KIND == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pm), "v"(pc));
-            if constexpr(KIND == 2) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
-            if constexpr(KIND == 3) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
-            if constexpr(KIND == 4) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pm));
-            if constexpr(KIND == 5) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pc));
-            if constexpr(KIND == 6) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[i]) : "v"(um));
-            if constexpr(KIND == 7) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
-            if constexpr(KIND == 8) asm volatile("v_rsq_f32 %0, %0" : "+v"(a[i]));
-            if constexpr(KIND == 9) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i]));
-            if constexpr(KIND == 10) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(u[i]) : "v"(um));
-            if constexpr(KIND == 11) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(u[i]));
-            if constexpr(KIND == 12) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(u[i]));
-            if constexpr(KIND == 13) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(u[i]) : "v"(um));
-            if constexpr(KIND == 16) asm volatile("v_cvt_f32_u32_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "+v"(u[i]));
-            if constexpr(KIND == 17) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(u[i]));
-            if constexpr(KIND == 18) asm volatile("v_alignbit_b32 %0, %1, %0, 9" : "+v"(u[i]) : "v"(um));
-            if constexpr(KIND == 19) asm volatile("v_cmp_le_f32 vcc, 0, %0" : : "v"(a[i]) : "vcc");
-            if constexpr(KIND == 20) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(um));
-            if constexpr(KIND == 21) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(u[i]) : "v"(um), "v"(um));
-            if constexpr(KIND == 22) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(u[i]) : "v"(um));
-            if constexpr(KIND == 23) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(u[i]) : "v"(um));
-            if constexpr(KIND == 24) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(u[i]) : "v"(a[i]), "v"(m));
-            if constexpr(KIND == 25) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(u[i]) : "v"(um));
-            if constexpr(KIND == 26) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(bank.v[0]), "v"(c));  // one scalar-register operand, the same every time
-            if constexpr(KIND == 27) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "s"(bank.v[0]), "v"(c));     // VOP2 form
-            if constexpr(KIND == 28) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
-            if constexpr(KIND == 29) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(a[i]) : "s"(bank.v[0]));
-            if constexpr(KIND == 30) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(bank.v[i % 16]), "v"(c));  // a different scalar register each time
-            if constexpr(KIND == 31) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "s"(bank.v[i % 16]), "v"(c));
-            if constexpr(KIND == 32) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(bank.v[i / 4]), "v"(c));   // each scalar register four times in a row
-            if constexpr(KIND == 33) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(bank.v[i / 2]), "v"(c));   // twice in a row
-            if constexpr(KIND == 34) asm volatile("v_add_u32 %0, %1, %0" : "+v"(u[i]) : "s"(bank.v[i % 16]));
-            if constexpr(KIND == 35) asm volatile("v_mov_b32 %0, %1" : "=v"(u[i]) : "s"(bank.v[i % 16]));
-            if constexpr(KIND == 36) asm volatile("v_mov_b32 %0, %1" : "=v"(u[i]) : "v"(um));
-            if constexpr(KIND == 14) a[i] = m / a[i];                    // IEEE-correct division
-            if constexpr(KIND == 15) a[i] = __builtin_sqrtf(a[i] + m);   // IEEE-correct sqrt (+1 add)
-        }
-    }
-    float s = 0.0f;
-#pragma unroll
-    for(int i = 0; i < kAcc; i++) s += a[i] + p[i].x + p[i].y + static_cast<float>(u[i]);
-    if(s == 123.456f) out[tid] = s;
-}
 
-template <int KIND>
-void run(const char *name, double flop_per_op, float *d_out) {
-    const int blocks = 256 * 8, threads = 256;
-    scalar_bank bank;
-    for(int i = 0; i < 16; i++) bank.v[i] = 0.9999f + 1e-6f * i;
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(probe<KIND>, dim3(blocks), dim3(threads), 0, 0, d_out, 1.0f, 12345u, bank);
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipEventRecord(e0));
-    const int reps = 5;
-    for(int r = 0; r < reps; r++) hipLaunchKernelGGL(probe<KIND>, dim3(blocks), dim3(threads), 0, 0, d_out, 1.0f, 12345u, bank);
-    HIPCHK(hipEventRecord(e1));
-    HIPCHK(hipEventSynchronize(e1));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-    const double lane_ops = static_cast<double>(blocks) * threads * kIters * kAcc * reps;
-    const double per_s = lane_ops / (ms * 1e-3);
-    // cycles per wave64 instruction per SIMD at 2.4 GHz: 1024 SIMDs, 64 lanes per instruction
-    const double cyc = 2.4e9 * 1024.0 * 64.0 / per_s;
-    std::printf("%-10s %8.3f ms  %7.2f T lane-ops/s  %7.2f TFLOP/s  %5.2f cyc/wave-instr/SIMD@2.4GHz\n", name, ms / reps,
-                per_s * 1e-12, per_s * flop_per_op * 1e-12, cyc);
-    HIPCHK(hipEventDestroy(e0));
-    HIPCHK(hipEventDestroy(e1));
+#define X4(B) B B B B
+PROBE_KERNEL(k_fma, X4(ROT16(I_FMA)))
+PROBE_KERNEL(k_fma_same_bank, X4(SAME16(I_FMA)))
+PROBE_KERNEL(k_fma_sgpr, X4(ROT16(I_FMA_S)))
+PROBE_KERNEL(k_fmac_sgpr, X4(ROT16(I_FMAC_S)))
+PROBE_KERNEL(k_mul, X4(ROT16(I_MUL)))
+PROBE_KERNEL(k_add, X4(ROT16(I_ADD)))
+PROBE_KERNEL(k_add_sgpr, X4(ROT16(I_ADD_S)))
+PROBE_KERNEL(k_pk_fma, X4(PAIR8(I_PKFMA)) X4(PAIR8(I_PKFMA)))
+PROBE_KERNEL(k_mul_lo_u32, X4(ROT16(I_MULLO)))
+PROBE_KERNEL(k_add_u32, X4(ROT16(I_ADDU)))
+PROBE_KERNEL(k_add_u32_sgpr, X4(ROT16(I_ADDU_S)))
+PROBE_KERNEL(k_xor, X4(ROT16(I_XOR)))
+PROBE_KERNEL(k_cvt_f32_u32, X4(ROT16(I_CVT)))
+PROBE_KERNEL(k_cvt_sdwa, X4(ROT16(I_CVT_SDWA)))
+PROBE_KERNEL(k_cmp_f32, X4(ROT16(I_CMP)))
+PROBE_KERNEL(k_rcp, X4(ROT16(I_RCP)))
+PROBE_KERNEL(k_sqrt, X4(ROT16(I_SQRT)))
+PROBE_KERNEL(k_max3, X4(ROT16(I_MAX3)))
+PROBE_KERNEL(k_mov_sgpr, X4(ROT16(I_MOV_S)))
+PROBE_KERNEL(k_camera_sample, ROT16(I_SAMPLE))      // 16 samples x 8 instructions = 128 per iteration
+
+typedef void (*probe_fn)(stamp *, int, float);
+
+void run(const char *name, probe_fn fn, int per_iteration, double flop_per_lane_op, int cus, double realtime_hz, stamp *d_out) {
+    for(int waves_per_simd : {1, 2, 4, 8}) {
+        const int blocks = cus * waves_per_simd;         // 256 threads = 4 waves, one per SIMD of a CU
+        const int n_waves = blocks * 4;
+        // size the loop for >= 50 ms: calibrate on a short run
+        int iters = 2000;
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        float ms = 0.0f;
+        for(int pass = 0; pass < 2; pass++) {
+            HIPCHK(hipEventRecord(e0));
+            hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, 0, d_out, iters, 0.9999f);
+            HIPCHK(hipEventRecord(e1));
+            HIPCHK(hipEventSynchronize(e1));
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            if(pass == 0) iters = static_cast<int>(iters * 60.0 / (ms > 0.01f ? ms : 0.01f));
+        }
+        std::vector<stamp> h(static_cast<size_t>(n_waves));
+        HIPCHK(hipMemcpy(h.data(), d_out, sizeof(stamp) * h.size(), hipMemcpyDeviceToHost));
+        double cycles = 0.0, ticks = 0.0;
+        for(const stamp &s : h) {
+            cycles += static_cast<double>(s.cycles);
+            ticks += static_cast<double>(s.ticks);
+        }
+        const double instr_per_wave = static_cast<double>(iters) * per_iteration;
+        const double clock_ghz = cycles / ticks * realtime_hz * 1e-9;
+        const double lane_ops = instr_per_wave * n_waves * 64.0 / (ms * 1e-3);
+        const double cyc_per_instr = clock_ghz * 1e9 * (cus * 4.0) * 64.0 / lane_ops;
+        std::printf("%-16s waves/SIMD %d  %6.3f cyc/wave-instr/SIMD  clock %5.3f GHz  %7.2f T lane-ops/s  %7.2f TFLOP/s  (%.1f ms)\n", name,
+                    waves_per_simd, cyc_per_instr, clock_ghz, lane_ops * 1e-12, lane_ops * flop_per_lane_op * 1e-12, ms);
+        HIPCHK(hipEventDestroy(e0));
+        HIPCHK(hipEventDestroy(e1));
+    }
 }
 
 int main() {
-    float *d_out = nullptr;
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_out), sizeof(float) * 256 * 8 * 256));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, 0));
-    std::printf("device %s CUs %d clock %d kHz\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate);
-    run<0>("fma", 2, d_out);
-    run<1>("pk_fma", 4, d_out);
-    run<2>("mul", 1, d_out);
-    run<3>("add", 1, d_out);
-    run<4>("pk_mul", 2, d_out);
-    run<5>("pk_add", 2, d_out);
-    run<6>("mul_lo_u32", 0, d_out);
-    run<7>("rcp", 1, d_out);
-    run<8>("rsq", 1, d_out);
-    run<9>("sqrt", 1, d_out);
-    run<10>("xor", 0, d_out);
-    run<11>("lshr", 0, d_out);
-    run<12>("cvt_f32_u32", 0, d_out);
-    run<13>("mad_u32_u24", 0, d_out);
-    run<16>("cvt_sdwa_w1", 0, d_out);
-    run<17>("cvt_ubyte1", 0, d_out);
-    run<18>("alignbit", 0, d_out);
-    run<19>("cmp_f32", 0, d_out);
-    run<20>("add_u32", 0, d_out);
-    run<21>("pk_fma_f16", 4, d_out);
-    run<22>("pk_add_f16", 2, d_out);
-    run<23>("pk_mul_f16", 2, d_out);
-    run<24>("cvt_pkrtz", 0, d_out);
-    run<25>("pk_max_f16", 0, d_out);
-    run<26>("fma_sgpr_op", 2, d_out);
-    run<27>("fmac_sgpr_op", 2, d_out);
-    run<28>("max3", 0, d_out);
-    run<30>("fma_sgpr_rot", 2, d_out);
-    run<31>("fmac_sgpr_rot", 2, d_out);
-    run<32>("fma_sgpr_x4", 2, d_out);
-    run<33>("fma_sgpr_x2", 2, d_out);
-    run<34>("add_u32_sgpr", 0, d_out);
-    run<35>("mov_from_sgpr", 0, d_out);
-    run<36>("mov_vgpr", 0, d_out);
-    run<29>("sub_sgpr_op", 1, d_out);
-    run<14>("div_ieee", 1, d_out);
-    run<15>("sqrt_ieee", 1, d_out);
+    int wall_khz = 0;
+    HIPCHK(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0));
+    const int cus = prop.multiProcessorCount;
+    std::printf("device %s CUs %d max clock %d kHz realtime clock %d kHz\n", prop.gcnArchName, cus, prop.clockRate, wall_khz);
+    stamp *d_out = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_out), sizeof(stamp) * static_cast<size_t>(cus) * 8 * 4));
+    const double hz = wall_khz * 1e3;
+    run("fma", k_fma, 64, 2, cus, hz, d_out);
+    run("fma_same_bank", k_fma_same_bank, 64, 2, cus, hz, d_out);
+    run("fma_sgpr_operand", k_fma_sgpr, 64, 2, cus, hz, d_out);
+    run("fmac_sgpr_operand", k_fmac_sgpr, 64, 2, cus, hz, d_out);
+    run("mul", k_mul, 64, 1, cus, hz, d_out);
+    run("add", k_add, 64, 1, cus, hz, d_out);
+    run("add_sgpr_operand", k_add_sgpr, 64, 1, cus, hz, d_out);
+    run("pk_fma", k_pk_fma, 64, 4, cus, hz, d_out);
+    run("mul_lo_u32", k_mul_lo_u32, 64, 0, cus, hz, d_out);
+    run("add_u32", k_add_u32, 64, 0, cus, hz, d_out);
+    run("add_u32_sgpr_op", k_add_u32_sgpr, 64, 0, cus, hz, d_out);
+    run("xor", k_xor, 64, 0, cus, hz, d_out);
+    run("cvt_f32_u32", k_cvt_f32_u32, 64, 0, cus, hz, d_out);
+    run("cvt_f32_u32_sdwa", k_cvt_sdwa, 64, 0, cus, hz, d_out);
+    run("cmp_f32", k_cmp_f32, 64, 0, cus, hz, d_out);
+    run("rcp", k_rcp, 64, 1, cus, hz, d_out);
+    run("sqrt", k_sqrt, 64, 1, cus, hz, d_out);
+    run("max3", k_max3, 64, 0, cus, hz, d_out);
+    run("mov_from_sgpr", k_mov_sgpr, 64, 0, cus, hz, d_out);
+    run("camera_sample_mix", k_camera_sample, 128, 1, cus, hz, d_out);
     HIPCHK(hipFree(d_out));
     return 0;
 }
