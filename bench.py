@@ -16,8 +16,12 @@ oracle, and to the reference wherever the reference defines the result) is timed
 run and reported under "exact".  --mode exact swaps the two.
 
 The line also carries
-  roofline      the kernel's algorithmic FP32 flops / its mean launch time (HIP events on the
-                launch stream, inside the timed region) against the FP32 vector peak,
+  roofline      the FP32 operations the kernel EXECUTES per launch (rocprofv3 counters
+                SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 of the same command, profiles/r02_counters.json:
+                64 x (ADD + MUL + 2 FMA + TRANS)) / its mean launch time (HIP events on the launch
+                stream, inside the timed region) against the FP32 vector peak -- a fraction that cannot
+                exceed 1; the flops of the reference's formulas for the same frame are reported beside
+                it as algorithmic_tflops / work_reduction,
   cpu_baseline  the CPU oracle (a port of the reference's pixel kernel extended with sampling)
                 timed on this host's cores on a bounded sample of the same frame, plus the real
                 reference binary's 1-sample figure where oracle/_ref was shipped,
@@ -44,14 +48,61 @@ sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT = 3840, 2160
 FP32_VECTOR_PEAK_TFLOPS = 157.3     # MI355X datasheet FP32 vector peak (256 CU x 256 flop/clk x 2.4 GHz)
-FP32_FMA_MEASURED_TFLOPS = 108.0    # what back-to-back v_fma_f32 sustains on this part (tools/valu_peak.hip)
-FP32_UNFUSED_MEASURED_TFLOPS = 54.0 # v_mul_f32 / v_add_f32 issue rate: the ceiling of code that may not fuse (exact build)
+# tools/valu_peak.hip (profiles/r02_valu_peak.txt): back-to-back v_fma_f32 / v_mul_f32 / v_add_f32 issue every
+# 2.19 shader clocks per SIMD at the 2.32 GHz the chip holds under that load: 69.4 T lane-operations/s.
+# Conversions, compares, 3-operand integer operations and anything with a scalar-register operand issue at
+# half that rate (4.22 clocks), v_rcp / v_sqrt / v_rsq at a quarter (8.24).
+VALU_FULL_RATE_MEASURED = 69.4e12
 HBM_PEAK_GBS = 8000.0
-VALU_ISSUE_MEASURED = 54.0e12       # lane-instructions/s that back-to-back v_fma_f32 / v_mul_f32 sustain (tools/valu_peak.hip)
-# VALU wave-instructions one launch of the default workload (4K, 1024 spp, one GPU) executes:
-# SQ_INSTS_VALU per launch in the committed rocprofv3 --pmc summaries
-EXECUTED_VALU_WAVE_INSTRUCTIONS = {"fast": (1521852812, "profiles/r01_f_bench_fast.txt"),
-                                   "exact": (5278682644, "profiles/r01_f_bench_exact.txt")}
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r02_counters.json")
+KERNEL_SOURCES = ["raytracer_amd/csrc/hip_raytracer_kernels.hip", "raytracer_amd/csrc/rt_exact_math.h"]
+
+
+def load_counters():
+    """profiles/r02_counters.json if it was measured on the kernels this tree holds, else the reason it is unusable."""
+    import hashlib
+
+    try:
+        with open(COUNTERS_FILE) as f:
+            doc = json.load(f)
+    except (OSError, ValueError) as exc:
+        return None, f"no counter file: {exc}"
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    if doc.get("kernel_source_sha256") != h.hexdigest():
+        return None, "profiles/r02_counters.json was collected on another version of the kernel sources: re-run tools/profile_bench.sh"
+    return doc, None
+
+
+def executed_work(doc, key, seconds_per_frame, share=1.0):
+    """Executed FP32 rate of workload `key` from the committed counters and this run's frame time.
+    `share`: fraction of the profiled frame one rank renders (tiles dealt round-robin: same mix of rows)."""
+    w = (doc or {}).get("workloads", {}).get(key)
+    if not w:
+        return None
+    flop = valu = 0.0
+    kernels = []
+    for name, k in w["kernels"].items():
+        if "executed_fp32_flop_per_frame" not in k:
+            continue
+        flop += k["executed_fp32_flop_per_frame"]
+        valu += k.get("SQ_INSTS_VALU", 0.0)
+        kernels.append(name)
+    if flop <= 0.0:
+        return None
+    flop *= share
+    valu *= share
+    out = {"fp32_flop_per_frame": flop, "tflops": flop / seconds_per_frame / 1e12, "kernels": sorted(kernels),
+           "source": f"profiles/r02_counters.json:{key}"}
+    if valu > 0.0:
+        lane_ops = valu * 64.0 / seconds_per_frame
+        out["valu_wave_instructions_per_frame"] = valu
+        out["valu_lane_ops_per_s"] = lane_ops
+        out["valu_issue_vs_measured_full_rate"] = lane_ops / VALU_FULL_RATE_MEASURED
+    return out
+
 
 # Algorithmic FP32 flops of the default-scene path pass, counted on the reference's formulas with
 # div and sqrt = 1 flop each and integer / compare / convert = 0:
@@ -115,6 +166,8 @@ def cpu_baseline(target_seconds: float):
             }
         except Exception as exc:  # the baseline must never take the benchmark down
             out["reference_1spp"] = {"error": str(exc)[:200]}
+    else:
+        out["reference_1spp"] = {"error": "oracle/_ref/raytracer_ref not built (make -C oracle ref needs the reference checkout)"}
     return out
 
 
@@ -259,9 +312,33 @@ def main():
 
     if rank == 0:
         paths_total = WIDTH * HEIGHT * args.spp
-        # every rank renders 1/world of the frame, the same mix of rows (tiles dealt round-robin)
-        flops = frame_flops(paths_total / world, WIDTH * HEIGHT / world)
-        achieved = flops / kernel_s / 1e12
+        counters, counters_error = load_counters()
+        headline = args.spp == 1024 and args.depth == 8          # the workload the counters were collected on
+
+        def roofline_of(mode, seconds, stats):
+            """Executed FP32 work (counters) over this run's kernel time; the reference formulas' flops beside it."""
+            # every rank renders 1/world of the frame, the same mix of rows (tiles dealt round-robin)
+            algorithmic = frame_flops(paths_total / world, WIDTH * HEIGHT / world) / seconds / 1e12
+            ex = executed_work(counters, f"headline_{mode}", seconds, 1.0 / world) if headline else None
+            r = {"bound": "valu_fp32", "achieved": ex["tflops"] if ex else None, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": ex["tflops"] / FP32_VECTOR_PEAK_TFLOPS if ex else None, "traffic": None,
+                 "kernel": "camera_hybrid_kernel" if mode == "fast" else "camera_kernel",
+                 "algorithmic_tflops": algorithmic, "vgprs": stats.vgprs, "lds_bytes": stats.lds_bytes}
+            if ex:
+                r["executed"] = ex
+                r["work_reduction"] = algorithmic / ex["tflops"]
+                k = counters["workloads"][f"headline_{mode}"]["kernels"].get(r["kernel"], {})
+                if "WRITE_SIZE" in k and "FETCH_SIZE" in k:
+                    # HBM bytes per launch: WRITE_SIZE in KiB; FETCH_SIZE in KiB, x2 on gfx950 (it under-reports wide reads)
+                    r["traffic"] = int((k["WRITE_SIZE"] * 1024 + k["FETCH_SIZE"] * 2048) / world)
+                r["note"] = ("achieved = 64 x (ADD_F32 + MUL_F32 + 2 FMA_F32 + TRANS_F32) wave-instructions per launch (rocprofv3 "
+                             "counters of this command, committed) / this run's launch time; algorithmic_tflops prices the flops of "
+                             "the reference's formulas (36 per missing sample, 67 per hit) over the same time and may exceed the "
+                             "peak: the kernel decides misses with a 4-fma per-pixel quadratic and never normalises their rays")
+            else:
+                r["note"] = counters_error or "executed-operation counters exist for the default workload (1024 spp, depth 8) only"
+            return r
+
         line = {
             "metric": "Mpaths/sec at 3840x2160",
             "value": paths_total / (elapsed / args.steps) / 1e6,
@@ -285,57 +362,18 @@ def main():
             "device": device_facts(torch, dev_index),
             "gathered_frame_equals_single_gpu_frame": verified,
             "rays_per_s": paths_total / (elapsed / args.steps),
-            "roofline": {
-                "bound": "valu_fp32",
-                "achieved": achieved,
-                "peak": FP32_VECTOR_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
-                # HBM bytes per launch from the PMC passes of the same command (profiles/r01_*_bench_*.txt:
-                # WRITE_SIZE 32400 KiB = 4 B x 8,294,400 px exactly, FETCH_SIZE ~0.1 MB after the gfx950 x2
-                # correction); a band of 1/N of the frame writes 1/N of it
-                "traffic": (33_177_600 + 114_000) // world,
-                "kernel": "camera_kernel",
-                "flop_per_launch": flops,
-                # algorithmic flops (the reference's formulas) over the rate back-to-back v_fma_f32
-                # sustains; can exceed 1 because the fast build executes fewer operations than the
-                # reference's formulas count (no normalisation of rays that miss, folded constants)
-                "algorithmic_vs_measured_fma_rate": achieved / FP32_FMA_MEASURED_TFLOPS,
-                "vgprs": st.vgprs,
-                "lds_bytes": st.lds_bytes,
-                "note": "achieved counts the flops of the reference's formulas per sample (36 miss / 67 hit); the "
-                        "kernels reach the same results with fewer operations (misses decided by a 5-fma quadratic "
-                        "per sample, no normalisation in the fast build), so frac can exceed 1; 'executed' prices "
-                        "the instructions really issued against the measured VALU issue rate",
-            },
+            "roofline": roofline_of(args.mode, kernel_s, st),
         }
-        if args.spp == 1024 and args.depth == 8:
-            count, source = EXECUTED_VALU_WAVE_INSTRUCTIONS[args.mode]
-            lane_ops = count * 64.0 / world / kernel_s
-            line["roofline"]["executed"] = {
-                "valu_wave_instructions_per_launch": count / world, "source": source,
-                "valu_instructions_per_sample": count * 64.0 / paths_total,
-                "valu_lane_ops_per_s": lane_ops, "measured_issue_ceiling": VALU_ISSUE_MEASURED,
-                "frac_of_issue_ceiling": lane_ops / VALU_ISSUE_MEASURED,
-            }
+        line["roofline"]["measured_full_rate_valu_lane_ops_per_s"] = VALU_FULL_RATE_MEASURED
         if second is not None:
             e2, k2, st2 = second
             steps2 = max(2, args.steps // 2)
-            a2 = flops / k2 / 1e12
-            unfused_mode_rate = a2 if other == "exact" else achieved
-            line["roofline"]["ceilings"] = {
-                "datasheet_fp32_vector": FP32_VECTOR_PEAK_TFLOPS, "measured_v_fma_f32": FP32_FMA_MEASURED_TFLOPS,
-                "measured_unfused_mul_add": FP32_UNFUSED_MEASURED_TFLOPS,
-                "exact_build_vs_unfused_ceiling": unfused_mode_rate / FP32_UNFUSED_MEASURED_TFLOPS,
-            }
             line[other] = {
                 "value": paths_total / (e2 / steps2) / 1e6, "unit": "Mpaths/s", "ms_per_step": e2 / steps2 * 1e3,
-                "kernel_ms": k2 * 1e3, "steps": steps2,
-                "roofline": {"bound": "valu_fp32", "achieved": a2, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": a2 / FP32_VECTOR_PEAK_TFLOPS, "vgprs": st2.vgprs},
+                "kernel_ms": k2 * 1e3, "steps": steps2, "roofline": roofline_of(other, k2, st2),
             }
         if world == 1 and not args.no_aux:
-            line["aux"] = aux_measurements(rt, torch, stream)
+            line["aux"] = aux_measurements(rt, torch, stream, counters)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)
@@ -344,7 +382,7 @@ def main():
         dist.destroy_process_group()
 
 
-def aux_measurements(rt, torch, stream):
+def aux_measurements(rt, torch, stream, counters):
     """Secondary kernels on one GPU, each against the roofline that bounds it."""
     from raytracer_amd import scenes
 
@@ -407,13 +445,15 @@ def aux_measurements(rt, torch, stream):
             img = torch.zeros((1080, 1920), dtype=torch.int32, device="cuda")
             best, s = settled_kernel_ms(back, img, torch, stream, launches=4 if depth == 1 else 2)
             tests = s.rays * len(sph)
-            tf = tests * 18.0 / (best * 1e-3) / 1e12
+            tf = tests * 18.0 / (best * 1e-3) / 1e12           # the reference's quadratic: 18 flop a test
+            ex = executed_work(counters, f"stress10k_1080p_{spp}spp_d{depth}_{mode}", best * 1e-3)
             out[f"stress10k_1080p_{spp}spp_depth{depth}_{mode}"] = {
                 "kernel_ms": best, "sphere_tests_per_s": tests / (best * 1e-3), "mpaths_per_s": s.paths / best / 1e3,
                 "rays_per_s": s.rays / (best * 1e-3), "rays_per_path": s.rays / s.paths,
                 "lane_utilisation": s.rays / s.lane_slots,
-                "roofline": {"bound": "valu_fp32", "achieved": tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": tf / FP32_VECTOR_PEAK_TFLOPS, "kernel": kernel},
+                "roofline": {"bound": "valu_fp32", "achieved": ex["tflops"] if ex else None, "peak": FP32_VECTOR_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": ex["tflops"] / FP32_VECTOR_PEAK_TFLOPS if ex else None, "kernel": kernel,
+                             "algorithmic_tflops": tf, "work_reduction": tf / ex["tflops"] if ex else None, "executed": ex},
             }
             back.close()
     # divergence-heavy scene (mixed diffuse / metal / dielectric, depth 50): lane utilisation of the
@@ -425,10 +465,15 @@ def aux_measurements(rt, torch, stream):
         back.setup(1920, 1080, spp=16, max_depth=50, seed=7, flags=flags, pass_=rt.PASS_PATH, spheres=sph)
         img = torch.zeros((1080, 1920), dtype=torch.int32, device="cuda")
         best, s = settled_kernel_ms(back, img, torch, stream, launches=3 if regen else 2)
-        out[f"divergence_1080p_16spp_depth50_{mode}" + ("" if regen else "_no_regeneration")] = {
+        entry = {
             "kernel_ms": best, "mpaths_per_s": s.paths / best / 1e3, "rays_per_s": s.rays / (best * 1e-3),
             "rays_per_path": s.rays / s.paths, "lane_utilisation": s.rays / s.lane_slots,
         }
+        ex = executed_work(counters, f"divergence_1080p_16spp_d50_{mode}", best * 1e-3) if regen else None
+        if ex:
+            entry["roofline"] = {"bound": "valu_fp32", "achieved": ex["tflops"], "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": ex["tflops"] / FP32_VECTOR_PEAK_TFLOPS, "executed": ex}
+        out[f"divergence_1080p_16spp_depth50_{mode}" + ("" if regen else "_no_regeneration")] = entry
         back.close()
     return out
 

@@ -17,7 +17,10 @@ def main():
     side = torch.cuda.Stream()          # a real stream: the library waits after every launch on the null stream
     torch.cuda.set_stream(side)
     stream = side.cuda_stream
-    for (w, h) in [(512, 512), (1920, 1080), (3840, 2160), (3838, 2160)]:      # the last: one pixel per lane (width not a multiple of 4)
+    sizes = [(512, 512), (1920, 1080), (3840, 2160), (3838, 2160)]      # the last: one pixel per lane (width not a multiple of 4)
+    if "--only-4k" in sys.argv:
+        sizes = [(3840, 2160)]      # counter passes: one launch shape per kernel, so per-kernel means mean something
+    for (w, h) in sizes:
         for fast in (False, True):
             back = rt.HipRaytracer(None)
             assert back.setup(w, h, flags=rt.FLAG_FAST if fast else 0, pass_=rt.PASS_PRIMARY)

@@ -1,17 +1,23 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for bench.py on the GPU box:
 #   1. --kernel-trace --stats      per-kernel durations (no counters)
-#   2..4 --pmc passes, one run each (counters never share a run with tracing domains)
+#   2..5 --pmc passes, one run each (counters never share a run with tracing domains):
+#        issue counters, executed FP32 operation counters, HBM read bytes, HBM write bytes
+# and folds the counters into profiles/r02_counters.json (tools/collect_counters.py).
 # Usage (from the repo root on the GPU box): tools/profile_bench.sh <mode> <outdir-under-gpurun_out>
 set -o pipefail
 MODE=${1:-exact}
 OUT=${GRAFT_REPO_ROOT:-$PWD}/gpurun_out/${2:-prof_$MODE}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
+STEPS=20; WARMUP=10
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --mode $MODE --steps 20 --warmup 10 --no-cpu-baseline --no-aux --no-second-mode"
+BENCH="python3 $ROOT/bench.py --mode $MODE --steps $STEPS --warmup $WARMUP --no-cpu-baseline --no-aux --no-second-mode"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY -d "$OUT/pmc_sq" -o pmc -- $BENCH > "$OUT/pmc_sq.log" 2>&1 || exit 2
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_SMEM GRBM_GUI_ACTIVE -d "$OUT/pmc_flops" -o pmc -- $BENCH > "$OUT/pmc_flops.log" 2>&1 || exit 5
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o pmc -- $BENCH > "$OUT/pmc_fetch.log" 2>&1 || exit 3
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE -d "$OUT/pmc_write" -o pmc -- $BENCH > "$OUT/pmc_write.log" 2>&1 || exit 4
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" -o pmc -- $BENCH > "$OUT/pmc_write.log" 2>&1 || exit 4
+cd "$ROOT" && mkdir -p gpurun_out/profiles_out && python3 tools/collect_counters.py headline_$MODE $((STEPS + WARMUP + 1)) "$OUT" || exit 6
+cp profiles/r02_counters.json gpurun_out/profiles_out/r02_counters.json
 echo profile_ok

@@ -41,7 +41,7 @@ def main():
             out.append(f"{r[0][:90]}\n    grid {r[1]}x{r[2]} wg {r[3]} vgpr {r[4]} agpr {r[5]} sgpr {r[6]} lds {r[7]} scratch {r[8]}"
                        f" | dur us min {r[9] / 1e3:.1f} avg {r[10] / 1e3:.1f} max {r[11] / 1e3:.1f} over {r[12]} launches")
         out.append("")
-    for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
+    for sub in ("pmc_sq", "pmc_flops", "pmc_fetch", "pmc_write"):
         db = os.path.join(src, sub, "pmc_results.db")
         if not os.path.exists(db):
             continue
@@ -50,13 +50,29 @@ def main():
                      "where kernel_name like '%path_kernel%' or kernel_name like '%primary_kernel%' or kernel_name like '%camera_kernel%' or kernel_name like '%camera_hybrid_kernel%' or kernel_name like '%ring_pixels_kernel%' "
                      "or kernel_name like '%path_stream%' or kernel_name like '%first_hit_kernel%' or kernel_name like '%resolve_block_kernel%' "
                      "group by kernel_name,counter_name")
+        last = None
+        flops = {}
         for kname, cname, val, n, dur in rows:
+            if kname != last:
+                out.append(f"  {kname[:120]}")
+                last = kname
+            if cname in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_TRANS_F32"):
+                flops[kname] = flops.get(kname, 0.0) + 64.0 * val
+                flops[(kname, "us")] = dur / 1e3
+            if cname == "SQ_INSTS_VALU_FMA_F32":
+                flops[kname] = flops.get(kname, 0.0) + 128.0 * val
             extra = ""
             if cname == "FETCH_SIZE":
                 extra = f"  -> HBM read bytes/launch (x1024 x2 gfx950 correction) = {val * 1024 * 2:.3e}"
             if cname == "WRITE_SIZE":
                 extra = f"  -> HBM write bytes/launch (x1024) = {val * 1024:.3e}"
             out.append(f"{cname:24s} {val:18.1f}  (n={n}, kernel avg {dur / 1e3:.1f} us){extra}")
+        for kname, total in flops.items():
+            if isinstance(kname, tuple):
+                continue
+            us = flops[(kname, "us")]
+            out.append(f"  executed FP32 flop/launch = 64 x (ADD + MUL + 2 FMA + TRANS) = {total:.4e}  -> {total / (us * 1e-6) / 1e12:.2f} TFLOP/s "
+                       f"= {total / (us * 1e-6) / 157.3e12:.3f} of the 157.3 TFLOP/s FP32 vector peak (this profiled run's {us:.1f} us)  [{kname[:60]}]")
         out.append("")
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     with open(dst, "w") as f:
