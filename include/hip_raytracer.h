@@ -148,6 +148,22 @@ int aehip_backend_trace(aehip_backend *backend);
  * queued on the device's null stream and which the call then waits on). */
 int aehip_backend_trace_device(aehip_backend *backend, uint32_t *argb_dev, float *rgba_dev, void *hip_stream);
 
+/* aehip_backend_trace_device for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
+ * reference.  Same arguments, same image bit for bit; the call makes no hipMalloc / hipFree and
+ * calls no allocating library routine: the scratch of the streamed path pass (per-path radiance
+ * of one block of samples, per-pixel block totals, the work-unit queue) and the ray counters live
+ * in a fixed array of AEHIP_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until
+ * the process ends.  A band whose strips do not fit the array at once is rendered in several
+ * passes over it; AEHIP_E_TOO_LARGE beyond 4096 passes (about 5.5 million 16x4-pixel strips at
+ * 64 or more samples per pixel).  The array keeps the last call's contents (the call clears
+ * what must start at zero); every call on a GPU shares that GPU's array, so calls that overlap
+ * on one GPU race -- issue them on one stream, or wait for one before starting the next.
+ * Passes that use no scratch (the reference's pass, the camera pass, the per-lane path pass
+ * without AEHIP_FLAG_COUNT_RAYS) run exactly as through aehip_backend_trace_device. */
+#define AEHIP_STATIC_SCRATCH_BYTES (64u << 20)
+int aehip_backend_trace_device_static(aehip_backend *backend, uint32_t *argb_dev, float *rgba_dev, void *hip_stream);
+
 int aehip_backend_stats(aehip_backend *backend, aehip_stats *out);
 
 /* One frame on `n_devices` GPUs of this node, driven from the calling thread; the multi-GPU form

@@ -85,6 +85,7 @@ EXPORTS = (
     "aehip_backend_setup",
     "aehip_backend_trace",
     "aehip_backend_trace_device",
+    "aehip_backend_trace_device_static",
     "aehip_backend_stats",
     "aehip_trace_frame",
 )
@@ -124,6 +125,7 @@ def load() -> ctypes.CDLL:
         L.aehip_backend_setup.argtypes = [vp, ctypes.POINTER(AehipScene), ctypes.POINTER(AehipParams)]
         L.aehip_backend_trace.argtypes = [vp]
         L.aehip_backend_trace_device.argtypes = [vp, vp, vp, vp]
+        L.aehip_backend_trace_device_static.argtypes = [vp, vp, vp, vp]
         L.aehip_backend_stats.argtypes = [vp, ctypes.POINTER(AehipStats)]
         L.aehip_trace_frame.argtypes = [ctypes.c_int, ctypes.POINTER(AehipScene), ctypes.POINTER(AehipParams), vp,
                                         ctypes.POINTER(AehipStats)]
@@ -203,6 +205,10 @@ class HipRaytracer:
 
     def trace_device(self, argb_ptr: int, rgba_ptr: int | None = None, stream: int | None = None) -> None:
         _check(self._lib.aehip_backend_trace_device(self._h, argb_ptr, rgba_ptr, stream), "aehip_backend_trace_device")
+
+    def trace_device_static(self, argb_ptr: int, rgba_ptr: int | None = None, stream: int | None = None) -> None:
+        """trace_device through the library's fixed scratch array: no device allocation in the call."""
+        _check(self._lib.aehip_backend_trace_device_static(self._h, argb_ptr, rgba_ptr, stream), "aehip_backend_trace_device_static")
 
     def stats(self) -> AehipStats:
         st = AehipStats()

@@ -923,6 +923,14 @@ struct radiance3 {
     float r, g, b;
 };
 
+// The strips one launch of the streamed pass works on, and where their paths' radiance goes: the
+// band's strips [begin, begin + count), sample `s` of the current block of pixel `p` of window
+// strip `w` at radiance[(w * stride + s) * 64 + p] (stride = samples per block the buffer holds
+// per strip).  A band with more strips than the scratch holds is rendered window after window.
+struct strip_window {
+    uint32_t begin, count, stride;
+};
+
 // First segments of the streamed pass.  Every path starts at the camera, so its first ray-list
 // walk can use the table of camera entries (4 operations a test instead of 10) if whole waves
 // walk it together: one wave per work unit, lane = pixel, the unit's samples one after the other.
@@ -933,17 +941,17 @@ __global__ __launch_bounds__(kBlock) void first_hit_kernel(view_consts vc, const
                                                            const float4 *__restrict__ camera_list,
                                                            const uint32_t *__restrict__ sample_terms,
                                                            radiance3 *__restrict__ radiance, uint32_t sample_begin,
-                                                           uint32_t sample_count, unsigned long long *ray_counter) {
+                                                           uint32_t sample_count, unsigned long long *ray_counter, strip_window win) {
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     const uint32_t strips_x = (vc.width + kTileW - 1) / kTileW;
-    const uint32_t strips_y = (vc.row_count + 3u) / 4u;
     const uint32_t chunks = (sample_count + kChunkSamples - 1u) / kChunkSamples;
-    const uint32_t n_strips = strips_x * strips_y;
+    const uint32_t n_strips = win.count;
     const uint32_t unit = blockIdx.x * (kBlock / 64) + wave;
     if(unit >= n_strips * chunks) return;
     const uint32_t chunk = unit / n_strips;
-    const uint32_t strip = unit - chunk * n_strips;
+    const uint32_t wstrip = unit - chunk * n_strips;       // strip of the window
+    const uint32_t strip = win.begin + wstrip;            // strip of the band
     const uint32_t sy = strip / strips_x;
     const uint32_t x = (strip - sy * strips_x) * kTileW + (lane & 15u);
     const uint32_t row = sy * 4u + (lane >> 4);
@@ -965,7 +973,7 @@ __global__ __launch_bounds__(kBlock) void first_hit_kernel(view_consts vc, const
         float closest = 3.402823466e+38f;
         int hit = -1;
         intersect_chunk<EXACT, true>(camera_list, vc.n_spheres, 0, ps.o, ps.d, a2, a4, closest, hit, geom);
-        if(valid) radiance[(static_cast<size_t>(strip) * AEHIP_SAMPLE_BLOCK + local) * 64u + lane] = radiance3{closest, __int_as_float(hit), 0.0f};
+        if(valid) radiance[(static_cast<size_t>(wstrip) * win.stride + local) * 64u + lane] = radiance3{closest, __int_as_float(hit), 0.0f};
     }
     if((vc.flags & AEHIP_FLAG_COUNT_RAYS) && lane == 0) atomicAdd(ray_counter + 1, 64ull * count);
 }
@@ -978,16 +986,15 @@ __global__ __launch_bounds__(kBlock) void path_stream_kernel(view_consts vc, con
                                                              const uint32_t *__restrict__ sample_terms,
                                                              radiance3 *__restrict__ radiance, uint32_t sample_begin,
                                                              uint32_t sample_count, unsigned long long *ray_counter,
-                                                             uint32_t *unit_queue, uint32_t unit_batch) {
+                                                             uint32_t *unit_queue, uint32_t unit_batch, strip_window win) {
     constexpr int kWaves = kBlock / 64;
     __shared__ uint32_t s_term[kWaves][64];          // per-pixel key terms of the unit being dealt
 
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     const uint32_t strips_x = (vc.width + kTileW - 1) / kTileW;
-    const uint32_t strips_y = (vc.row_count + 3u) / 4u;
     const uint32_t chunks = (sample_count + kChunkSamples - 1u) / kChunkSamples;     // units per strip
-    const uint32_t n_strips = strips_x * strips_y;
+    const uint32_t n_strips = win.count;
     const uint32_t n_units = n_strips * chunks;
 
     // wave-uniform state
@@ -1026,14 +1033,15 @@ __global__ __launch_bounds__(kBlock) void path_stream_kernel(view_consts vc, con
                 } else {
                     const uint32_t id = batch_next++;
                     const uint32_t chunk = id / n_strips;
-                    const uint32_t new_strip = id - chunk * n_strips;
+                    const uint32_t new_strip = id - chunk * n_strips;       // strip of the window
                     chunk_begin = chunk * kChunkSamples;
                     pool = 64u * min(kChunkSamples, sample_count - chunk_begin);
                     cursor = 0;
                     if(new_strip != strip) {
                         strip = new_strip;
-                        const uint32_t sy = strip / strips_x;
-                        strip_x0 = (strip - sy * strips_x) * kTileW;
+                        const uint32_t band_strip = win.begin + strip;
+                        const uint32_t sy = band_strip / strips_x;
+                        strip_x0 = (band_strip - sy * strips_x) * kTileW;
                         strip_row0 = sy * 4u;
                         __builtin_amdgcn_wave_barrier();
                         s_term[wave][lane] = pixel_term(vc.seed_hash, image_row(vc, strip_row0 + (lane >> 4)) * vc.width + strip_x0 + (lane & 15u));
@@ -1053,7 +1061,7 @@ __global__ __launch_bounds__(kBlock) void path_stream_kernel(view_consts vc, con
                     const uint32_t row = strip_row0 + (pix >> 4);
                     if(x < vc.width && row < vc.row_count) {
                         y = image_row(vc, row);
-                        slot = (static_cast<size_t>(strip) * AEHIP_SAMPLE_BLOCK + local) * 64u + pix;
+                        slot = (static_cast<size_t>(strip) * win.stride + local) * 64u + pix;
                         start_path<EXACT>(vc, s_term[wave][pix], sample_terms, x, y, sample_begin + local, ps);
                         tracing = true;
                     }
@@ -1111,16 +1119,15 @@ __global__ __launch_bounds__(kBlock) void path_stream_first_hits_kernel(view_con
                                                              const uint32_t *__restrict__ sample_terms,
                                                              radiance3 *__restrict__ radiance, uint32_t sample_begin,
                                                              uint32_t sample_count, unsigned long long *ray_counter,
-                                                             uint32_t *unit_queue, uint32_t unit_batch, uint32_t deal_rounds) {
+                                                             uint32_t *unit_queue, uint32_t unit_batch, strip_window win, uint32_t deal_rounds) {
     constexpr int kWaves = kBlock / 64;
     __shared__ uint32_t s_term[kWaves][64];          // per-pixel key terms of the unit being dealt
 
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
     const uint32_t strips_x = (vc.width + kTileW - 1) / kTileW;
-    const uint32_t strips_y = (vc.row_count + 3u) / 4u;
     const uint32_t chunks = (sample_count + kChunkSamples - 1u) / kChunkSamples;     // units per strip
-    const uint32_t n_strips = strips_x * strips_y;
+    const uint32_t n_strips = win.count;
     const uint32_t n_units = n_strips * chunks;
 
     // wave-uniform state
@@ -1165,14 +1172,15 @@ __global__ __launch_bounds__(kBlock) void path_stream_first_hits_kernel(view_con
             } else {
                 const uint32_t id = batch_next++;
                 const uint32_t chunk = id / n_strips;
-                const uint32_t new_strip = id - chunk * n_strips;
+                const uint32_t new_strip = id - chunk * n_strips;       // strip of the window
                 chunk_begin = chunk * kChunkSamples;
                 pool = 64u * min(kChunkSamples, sample_count - chunk_begin);
                 cursor = 0;
                 if(new_strip != strip) {
                     strip = new_strip;
-                    const uint32_t sy = strip / strips_x;
-                    strip_x0 = (strip - sy * strips_x) * kTileW;
+                    const uint32_t band_strip = win.begin + strip;
+                    const uint32_t sy = band_strip / strips_x;
+                    strip_x0 = (band_strip - sy * strips_x) * kTileW;
                     strip_row0 = sy * 4u;
                     __builtin_amdgcn_wave_barrier();
                     s_term[wave][lane] = pixel_term(vc.seed_hash, image_row(vc, strip_row0 + (lane >> 4)) * vc.width + strip_x0 + (lane & 15u));
@@ -1192,7 +1200,7 @@ __global__ __launch_bounds__(kBlock) void path_stream_first_hits_kernel(view_con
                 const uint32_t row = strip_row0 + (pix >> 4);
                 if(x < vc.width && row < vc.row_count) {
                     y = image_row(vc, row);
-                    slot = (static_cast<size_t>(strip) * AEHIP_SAMPLE_BLOCK + local) * 64u + pix;
+                    slot = (static_cast<size_t>(strip) * win.stride + local) * 64u + pix;
                     start_path<EXACT>(vc, s_term[wave][pix], sample_terms, x, y, sample_begin + local, ps);
                     tracing = true;
                     const radiance3 first = radiance[slot];
@@ -1270,18 +1278,18 @@ __global__ __launch_bounds__(kBlock) void path_stream_first_hits_kernel(view_con
 __global__ __launch_bounds__(kBlock) void resolve_block_kernel(view_consts vc, const radiance3 *__restrict__ radiance,
                                                                radiance3 *__restrict__ totals, uint32_t sample_count,
                                                                uint32_t first_block, uint32_t last_block,
-                                                               uint32_t *__restrict__ argb, float4 *__restrict__ rgba) {
+                                                               uint32_t *__restrict__ argb, float4 *__restrict__ rgba, strip_window win) {
     const uint32_t strips_x = (vc.width + kTileW - 1) / kTileW;
-    const uint32_t strips_y = (vc.row_count + 3u) / 4u;
-    const uint32_t strip = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t wstrip = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);       // strip of the window
     const uint32_t lane = threadIdx.x & 63u;
-    if(strip >= strips_x * strips_y) return;
+    if(wstrip >= win.count) return;
+    const uint32_t strip = win.begin + wstrip;
     const uint32_t sy = strip / strips_x;
     const uint32_t x = (strip - sy * strips_x) * kTileW + (lane & 15u);
     const uint32_t row = sy * 4u + (lane >> 4);
     if(x >= vc.width || row >= vc.row_count) return;
 
-    const radiance3 *p = radiance + static_cast<size_t>(strip) * AEHIP_SAMPLE_BLOCK * 64u + lane;
+    const radiance3 *p = radiance + static_cast<size_t>(wstrip) * win.stride * 64u + lane;
     f3 block = {0.0f, 0.0f, 0.0f};
     for(uint32_t s = 0; s < sample_count; s++) {
         const radiance3 v = p[static_cast<size_t>(s) * 64u];
@@ -1290,9 +1298,10 @@ __global__ __launch_bounds__(kBlock) void resolve_block_kernel(view_consts vc, c
         block.z += v.b;
     }
     const size_t idx = static_cast<size_t>(row) * vc.width + x;
+    const size_t tidx = static_cast<size_t>(wstrip) * 64u + lane;        // totals: per pixel of the window
     f3 sum = {0.0f, 0.0f, 0.0f};
     if(!first_block) {
-        const radiance3 t = totals[idx];
+        const radiance3 t = totals[tidx];
         sum = f3{t.r, t.g, t.b};
     }
     sum.x += block.x;
@@ -1306,7 +1315,7 @@ __global__ __launch_bounds__(kBlock) void resolve_block_kernel(view_consts vc, c
         argb[idx] = pack_argb32(r, g, b);
         if(rgba) rgba[idx] = make_float4(r, g, b, 1.0f);
     } else {
-        totals[idx] = radiance3{sum.x, sum.y, sum.z};
+        totals[tidx] = radiance3{sum.x, sum.y, sum.z};
     }
 }
 
@@ -1831,6 +1840,44 @@ int fail(int code, const char *fmt, ...) {
 
 }  // namespace
 
+namespace {
+// Scratch of the streamed pass and of the ray counters: three 64-bit words (ray segments, lane
+// slots, the unit queue's cursor), the radiance block of a window of strips, the per-pixel sums of
+// the window's finished blocks.  A backend's own (allocated by set-up, at most kScratchBudget) or,
+// for aehip_backend_trace_device_static, the fixed array below, one copy per GPU.
+constexpr size_t kScratchBudget = static_cast<size_t>(448) << 20;       // radiance + totals a backend allocates at most
+constexpr size_t kStaticScratchBytes = AEHIP_STATIC_SCRATCH_BYTES;
+constexpr size_t kScratchHeader = 256;                                  // counters, and alignment of what follows
+constexpr uint32_t kMaxStaticWindows = 4096;                           // windows a call through the static scratch may take
+static __device__ __align__(256) unsigned char g_static_scratch[kStaticScratchBytes];
+// Device address of the array on each GPU (every GPU holds its own copy at its own address), looked
+// up once per device with that device current; host code never uses the array's name as a pointer.
+constexpr int kMaxDevices = 64;
+unsigned char *g_static_scratch_ptr[kMaxDevices] = {};
+
+hipError_t resolve_static_scratch(int device) {        // `device` must be current
+    if(device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    if(g_static_scratch_ptr[device]) return hipSuccess;
+    void *ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_static_scratch));
+    if(e == hipSuccess) g_static_scratch_ptr[device] = static_cast<unsigned char *>(ptr);
+    return e;
+}
+
+struct stream_scratch {
+    unsigned long long *counters = nullptr;      // [0] ray segments, [1] lane slots, [2] unit queue
+    radiance3 *radiance = nullptr;
+    radiance3 *totals = nullptr;
+    uint32_t window_strips = 0;                  // strips the radiance / totals hold
+    uint32_t stride = 0;                         // samples per strip the radiance holds
+};
+
+// bytes of radiance + totals per strip for a request of `spp` samples per pixel
+inline uint32_t scratch_stride(uint32_t spp) { return spp < AEHIP_SAMPLE_BLOCK ? spp : AEHIP_SAMPLE_BLOCK; }
+inline size_t scratch_bytes_per_strip(uint32_t spp) { return (static_cast<size_t>(scratch_stride(spp)) * 64u + 64u) * sizeof(radiance3); }
+
+}  // namespace
+
 struct aehip_backend {
     int device = 0;
     int cu_count = 1;                        // compute units of the device
@@ -1855,15 +1902,18 @@ struct aehip_backend {
     size_t argb_capacity = 0;                // pixels
     uint32_t *h_staging = nullptr;           // pinned
     size_t staging_capacity = 0;
-    unsigned long long *d_rays = nullptr;    // ray segments, lane slots, strip queue of the streamed pass
+    unsigned long long *d_rays = nullptr;    // ray segments, lane slots, unit queue of the streamed pass
     uint32_t *d_sample_terms = nullptr;      // spp + 1 words: per-sample key terms (+1 spare for prefetch)
     uint32_t sample_terms_capacity = 0;
     uint32_t *d_ring = nullptr;              // fast single-sphere camera pass: pixels the exact kernel redoes, sorted by band row
     uint32_t ring_capacity = 0, ring_count = 0;
     std::vector<uint32_t> ring_row_offset;   // entries before band row r (size rows + 1)
-    radiance3 *d_radiance = nullptr;         // streamed pass: one block of per-path radiance
-    radiance3 *d_totals = nullptr;           //   and the per-pixel sums of finished blocks
-    size_t radiance_capacity = 0, totals_capacity = 0;   // in elements
+    radiance3 *d_radiance = nullptr;         // streamed pass: a window's block of per-path radiance, then its
+    size_t radiance_capacity = 0;            //   per-pixel sums of finished blocks; one allocation, size in bytes
+    uint32_t window_strips = 0;              // strips of the band the allocation holds at the request's samples per pixel
+    bool wants_streamed_pass = false;        // the request goes through the streamed pass (decided by set-up)
+    hipEvent_t ev_scratch = nullptr;         // end of the last launch that used the scratch or the counters
+    unsigned long long *last_counters = nullptr;     // where the last launch counted rays (own or static scratch)
 
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;       // device -> host copies of finished parts of a frame (aehip_backend_trace)
@@ -1887,7 +1937,18 @@ bool takes_streamed_pass(const aehip_backend *b) {
     // than that, i.e. for all but the smallest shape lists.
     // (Paths of one segment all end together: nothing to stream, the per-lane pass is leaner.)
     return b->params.list_source != 1u && !(vc.flags & AEHIP_FLAG_NO_REGEN) && vc.n_spheres >= kPoolMinSpheres &&
-           vc.max_depth > 1 && b->d_radiance != nullptr;
+           vc.max_depth > 1;
+}
+
+// the backend's own scratch, as set-up sized it
+stream_scratch own_scratch(const aehip_backend *b) {
+    stream_scratch sc;
+    sc.counters = b->d_rays;
+    sc.stride = scratch_stride(b->vc.spp);
+    sc.window_strips = b->window_strips;
+    sc.radiance = b->d_radiance;
+    sc.totals = b->d_radiance ? b->d_radiance + static_cast<size_t>(sc.window_strips) * sc.stride * 64u : nullptr;
+    return sc;
 }
 
 // Does the camera pass run its single-sphere variant (sphere constants in scalar registers, hits
@@ -1932,13 +1993,18 @@ int build_ring_list(aehip_backend *b) {
     return AEHIP_OK;
 }
 
-int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t stream) {
+int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t stream, const stream_scratch &scratch) {
     const view_consts &vc = b->vc;
+    // Launches of one backend share one scratch: a launch that uses it (the streamed pass, the ray
+    // counters) is ordered after the last one that did, whatever streams the two were given.
+    const bool uses_scratch = (vc.flags & AEHIP_FLAG_COUNT_RAYS) || takes_streamed_pass(b);
+    if(uses_scratch) AEHIP_CHECK(hipStreamWaitEvent(stream, b->ev_scratch, 0));
     const bool exact = !(vc.flags & AEHIP_FLAG_FAST);
     float4 *rgba = reinterpret_cast<float4 *>(rgba_dev);
     const void *func = nullptr;
 
-    if(vc.flags & AEHIP_FLAG_COUNT_RAYS) AEHIP_CHECK(hipMemsetAsync(b->d_rays, 0, 2 * sizeof(unsigned long long), stream));
+    if(vc.flags & AEHIP_FLAG_COUNT_RAYS) AEHIP_CHECK(hipMemsetAsync(scratch.counters, 0, 2 * sizeof(unsigned long long), stream));
+    b->last_counters = scratch.counters;
     b->counts_known = false;
 
     if(b->params.pass == AEHIP_PASS_PRIMARY) {
@@ -2012,7 +2078,7 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
     do {                                                                                                               \
         func = reinterpret_cast<const void *>(path_kernel<E, L>);                                                      \
         hipLaunchKernelGGL((path_kernel<E, L>), grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_matl, b->d_kind,    \
-                           b->d_sample_terms, argb_dev, rgba, b->d_rays, b->d_camera);                                 \
+                           b->d_sample_terms, argb_dev, rgba, scratch.counters, b->d_camera);                          \
     } while(0)
         if(takes_streamed_pass(b)) {
             // persistent waves: no more workgroups than the chip holds at once (a larger grid
@@ -2041,25 +2107,33 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
             // takes are 1.7 ms of a 1080p 16-spp launch), so cheap units are taken several at a
             // time; costly ones singly, for the finest balance at the end of the launch.
             const uint32_t unit_batch = std::min(16u, std::max(1u, 128u / vc.n_spheres));
-            for(uint32_t blk = 0; blk < nblocks; blk++) {
-                const uint32_t begin = blk * AEHIP_SAMPLE_BLOCK;
-                const uint32_t count = std::min(AEHIP_SAMPLE_BLOCK, vc.spp - begin);
-                const uint64_t units = static_cast<uint64_t>(strips) * ((count + kChunkSamples - 1u) / kChunkSamples);
-                const uint32_t groups = static_cast<uint32_t>(std::min<uint64_t>(resident, (units + 3u) / 4u));
-                AEHIP_CHECK(hipMemsetAsync(b->d_rays + 2, 0, sizeof(unsigned long long), stream));
-                if(first_hits) {
-                    const dim3 first_grid(static_cast<uint32_t>((units + 3u) / 4u));
-                    if(exact) hipLaunchKernelGGL(first_hit_kernel<true>, first_grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_camera, b->d_sample_terms, b->d_radiance, begin, count, b->d_rays);
-                    else hipLaunchKernelGGL(first_hit_kernel<false>, first_grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_camera, b->d_sample_terms, b->d_radiance, begin, count, b->d_rays);
+            if(!scratch.radiance || !scratch.totals || !scratch.counters || scratch.window_strips == 0 || scratch.stride < scratch_stride(vc.spp))
+                return fail(AEHIP_E_INVALID, "streamed pass without scratch (set-up did not size it for this request)");
+            uint32_t *queue = reinterpret_cast<uint32_t *>(scratch.counters + 2);
+            // window after window of strips, each through all its sample blocks
+            for(uint32_t first = 0; first < strips; first += scratch.window_strips) {
+                const strip_window win{first, std::min(scratch.window_strips, strips - first), scratch.stride};
+                for(uint32_t blk = 0; blk < nblocks; blk++) {
+                    const uint32_t begin = blk * AEHIP_SAMPLE_BLOCK;
+                    const uint32_t count = std::min(AEHIP_SAMPLE_BLOCK, vc.spp - begin);
+                    const uint64_t units = static_cast<uint64_t>(win.count) * ((count + kChunkSamples - 1u) / kChunkSamples);
+                    const uint32_t groups = static_cast<uint32_t>(std::min<uint64_t>(resident, (units + 3u) / 4u));
+                    AEHIP_CHECK(hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream));
+                    if(first_hits) {
+                        const dim3 first_grid(static_cast<uint32_t>((units + 3u) / 4u));
+                        if(exact) hipLaunchKernelGGL(first_hit_kernel<true>, first_grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_camera, b->d_sample_terms, scratch.radiance, begin, count, scratch.counters, win);
+                        else hipLaunchKernelGGL(first_hit_kernel<false>, first_grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_camera, b->d_sample_terms, scratch.radiance, begin, count, scratch.counters, win);
+                    }
+                    radiance3 *radiance = scratch.radiance;
+                    unsigned long long *counters = scratch.counters;
+                    void *args[] = {const_cast<view_consts *>(&vc), &b->d_geom, &b->d_prefilter, &b->d_matl, &b->d_kind, &b->d_sample_terms,
+                                    &radiance, const_cast<uint32_t *>(&begin), const_cast<uint32_t *>(&count), &counters, &queue,
+                                    const_cast<uint32_t *>(&unit_batch), const_cast<strip_window *>(&win), const_cast<uint32_t *>(&deal_rounds)};
+                    // (the kernel without first hits has no last parameter and ignores the extra entry)
+                    AEHIP_CHECK(hipLaunchKernel(func, dim3(groups), dim3(kBlock), args, 0, stream));
+                    hipLaunchKernelGGL(resolve_block_kernel, dim3((win.count + 3u) / 4u), dim3(kBlock), 0, stream, vc, scratch.radiance, scratch.totals,
+                                       count, blk == 0 ? 1u : 0u, blk + 1 == nblocks ? 1u : 0u, argb_dev, rgba, win);
                 }
-                uint32_t *queue = reinterpret_cast<uint32_t *>(b->d_rays + 2);
-                void *args[] = {const_cast<view_consts *>(&vc), &b->d_geom, &b->d_prefilter, &b->d_matl, &b->d_kind, &b->d_sample_terms,
-                                &b->d_radiance, const_cast<uint32_t *>(&begin), const_cast<uint32_t *>(&count), &b->d_rays, &queue,
-                                const_cast<uint32_t *>(&unit_batch), const_cast<uint32_t *>(&deal_rounds)};
-                // (the kernel without first hits has no last parameter and ignores the extra entry)
-                AEHIP_CHECK(hipLaunchKernel(func, dim3(groups), dim3(kBlock), args, 0, stream));
-                hipLaunchKernelGGL(resolve_block_kernel, dim3((strips + 3u) / 4u), dim3(kBlock), 0, stream, vc, b->d_radiance, b->d_totals,
-                                   count, blk == 0 ? 1u : 0u, blk + 1 == nblocks ? 1u : 0u, argb_dev, rgba);
             }
         } else if(exact) {
             if(list == kListLdsOnce) AEHIP_LAUNCH_PATH(true, kListLdsOnce);
@@ -2073,6 +2147,7 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
 #undef AEHIP_LAUNCH_PATH
     }
     AEHIP_CHECK(hipGetLastError());
+    if(uses_scratch) AEHIP_CHECK(hipEventRecord(b->ev_scratch, stream));
 
     // resource figures of the kernel just launched; queried once per kernel and backend, not per launch
     if(func != b->attr_func) {
@@ -2129,6 +2204,7 @@ int aehip_backend_create(int device, uint32_t *framebuffer, aehip_backend **out)
     b->framebuffer = framebuffer;
 
     hipError_t e = hipSetDevice(device);
+    if(e == hipSuccess) e = resolve_static_scratch(device);
     if(e == hipSuccess) e = hipDeviceGetAttribute(&b->cu_count, hipDeviceAttributeMultiprocessorCount, device);
     // a blocking stream: ordered after whatever the caller queued on the device's null stream
     // (a buffer it just cleared, say) before handing us that buffer
@@ -2136,6 +2212,7 @@ int aehip_backend_create(int device, uint32_t *framebuffer, aehip_backend **out)
     if(e == hipSuccess) e = hipEventCreate(&b->ev_begin);
     if(e == hipSuccess) e = hipEventCreate(&b->ev_end);
     if(e == hipSuccess) e = hipEventCreate(&b->ev_copy);
+    if(e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_scratch, hipEventDisableTiming);
     if(e == hipSuccess) e = hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking);
     for(int k = 0; k < kTraceParts && e == hipSuccess; k++) {
         e = hipEventCreateWithFlags(&b->ev_part_done[k], hipEventDisableTiming);
@@ -2165,7 +2242,7 @@ void aehip_backend_destroy(aehip_backend *b) {
     if(b->d_rays) (void)hipFree(b->d_rays);
     if(b->d_sample_terms) (void)hipFree(b->d_sample_terms);
     if(b->d_radiance) (void)hipFree(b->d_radiance);
-    if(b->d_totals) (void)hipFree(b->d_totals);
+    if(b->ev_scratch) (void)hipEventDestroy(b->ev_scratch);
     if(b->h_staging) (void)hipHostFree(b->h_staging);
     if(b->ev_begin) (void)hipEventDestroy(b->ev_begin);
     if(b->ev_end) (void)hipEventDestroy(b->ev_end);
@@ -2371,40 +2448,26 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
         if(e != hipSuccess) return fail(AEHIP_E_HIP, "scene upload: %s", hipGetErrorString(e));
     }
 
-    // buffers of the streamed pass (see launch()): a block of per-path radiance and the
-    // per-pixel totals; scenes it does not serve, or images beyond the memory budget, keep the
-    // per-lane pass
+    // scratch of the streamed pass (see launch()): the radiance block and block totals of a window
+    // of strips, the whole band if it fits kScratchBudget
     {
-        const bool wanted = p.pass == AEHIP_PASS_PATH && p.list_source != 1u &&
-                            !(p.flags & AEHIP_FLAG_NO_REGEN) && vc.n_spheres >= kPoolMinSpheres && p.max_depth > 1 &&
-                            !(b->all_terminal && vc.n_spheres <= static_cast<uint32_t>(kLdsSpheres));
-        const size_t strips = static_cast<size_t>((p.width + kTileW - 1) / kTileW) * ((p.row_count + 3u) / 4u);
-        const size_t need = strips * 64u * AEHIP_SAMPLE_BLOCK;
-        const size_t pixels = static_cast<size_t>(p.width) * p.row_count;
-        constexpr size_t kBudget = (static_cast<size_t>(32) << 30) / sizeof(radiance3);       // 32 GiB
-        if(!wanted || need > kBudget) {
-            if(b->d_radiance) (void)hipFree(b->d_radiance);
-            if(b->d_totals) (void)hipFree(b->d_totals);
-            b->d_radiance = nullptr; b->d_totals = nullptr;
-            b->radiance_capacity = 0; b->totals_capacity = 0;
-        } else {
-            // a failed allocation is not an error: the per-lane pass needs no such buffer
+        b->params = p;                  // takes_streamed_pass() reads the request
+        const bool wanted = takes_streamed_pass(b);
+        b->wants_streamed_pass = wanted;
+        if(wanted) {
+            const size_t strips = static_cast<size_t>((p.width + kTileW - 1) / kTileW) * ((p.row_count + 3u) / 4u);
+            const size_t per_strip = scratch_bytes_per_strip(p.spp);
+            const size_t window = std::min(strips, std::max<size_t>(1, kScratchBudget / per_strip));
+            const size_t need = window * per_strip;
             if(need > b->radiance_capacity) {
                 if(b->d_radiance) (void)hipFree(b->d_radiance);
                 b->d_radiance = nullptr; b->radiance_capacity = 0;
-                if(hipMalloc(reinterpret_cast<void **>(&b->d_radiance), need * sizeof(radiance3)) == hipSuccess) b->radiance_capacity = need;
-                else { b->d_radiance = nullptr; (void)hipGetLastError(); }
+                AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_radiance), need));
+                b->radiance_capacity = need;
             }
-            if(b->d_radiance && pixels > b->totals_capacity) {
-                if(b->d_totals) (void)hipFree(b->d_totals);
-                b->d_totals = nullptr; b->totals_capacity = 0;
-                if(hipMalloc(reinterpret_cast<void **>(&b->d_totals), pixels * sizeof(radiance3)) == hipSuccess) b->totals_capacity = pixels;
-                else {
-                    b->d_totals = nullptr; (void)hipGetLastError();
-                    (void)hipFree(b->d_radiance);
-                    b->d_radiance = nullptr; b->radiance_capacity = 0;
-                }
-            }
+            b->window_strips = static_cast<uint32_t>(window);
+        } else {
+            b->window_strips = 0;
         }
     }
 
@@ -2448,7 +2511,39 @@ int aehip_backend_trace_device(aehip_backend *b, uint32_t *argb_dev, float *rgba
     const bool own = hip_stream == nullptr;
     hipStream_t stream = own ? b->stream : static_cast<hipStream_t>(hip_stream);
     AEHIP_CHECK(hipEventRecord(b->ev_begin, stream));
-    const int rc = launch(b, argb_dev, rgba_dev, stream);
+    const int rc = launch(b, argb_dev, rgba_dev, stream, own_scratch(b));
+    if(rc != AEHIP_OK) return rc;
+    AEHIP_CHECK(hipEventRecord(b->ev_end, stream));
+    b->timed_on_own_stream = own;
+    if(own) AEHIP_CHECK(hipStreamSynchronize(stream));
+    return AEHIP_OK;
+}
+
+int aehip_backend_trace_device_static(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, void *hip_stream) {
+    if(!b) return fail(AEHIP_E_INVALID, "aehip_backend_trace_device_static: backend is null");
+    if(!b->ready) return fail(AEHIP_E_NOT_SETUP, "trace before a successful setup");
+    if(!argb_dev) return fail(AEHIP_E_INVALID, "argb_dev is null");
+    AEHIP_CHECK(hipSetDevice(b->device));
+    unsigned char *base = (b->device >= 0 && b->device < kMaxDevices) ? g_static_scratch_ptr[b->device] : nullptr;
+    if(!base) return fail(AEHIP_E_HIP, "the static scratch has no address on device %d", b->device);
+    // layout: counters | radiance of a window of strips | the window's block totals
+    stream_scratch sc;
+    sc.counters = reinterpret_cast<unsigned long long *>(base);
+    sc.stride = scratch_stride(b->vc.spp);
+    if(takes_streamed_pass(b)) {
+        const size_t strips = static_cast<size_t>((b->vc.width + kTileW - 1) / kTileW) * ((b->vc.row_count + 3u) / 4u);
+        const size_t window = (kStaticScratchBytes - kScratchHeader) / scratch_bytes_per_strip(b->vc.spp);
+        if(window == 0 || strips > window * kMaxStaticWindows)
+            return fail(AEHIP_E_TOO_LARGE, "a band of %zu strips of 16x4 pixels at %u samples per pixel needs more than %u passes through the %zu MiB static scratch",
+                        strips, b->vc.spp, kMaxStaticWindows, kStaticScratchBytes >> 20);
+        sc.window_strips = static_cast<uint32_t>(std::min(window, strips));
+        sc.radiance = reinterpret_cast<radiance3 *>(base + kScratchHeader);
+        sc.totals = sc.radiance + static_cast<size_t>(sc.window_strips) * sc.stride * 64u;
+    }
+    const bool own = hip_stream == nullptr;
+    hipStream_t stream = own ? b->stream : static_cast<hipStream_t>(hip_stream);
+    AEHIP_CHECK(hipEventRecord(b->ev_begin, stream));
+    const int rc = launch(b, argb_dev, rgba_dev, stream, sc);
     if(rc != AEHIP_OK) return rc;
     AEHIP_CHECK(hipEventRecord(b->ev_end, stream));
     b->timed_on_own_stream = own;
@@ -2509,7 +2604,7 @@ int aehip_backend_trace(aehip_backend *b) {
         const size_t offset = static_cast<size_t>(r0) * width, count = static_cast<size_t>(r1 - r0) * width;
         b->vc.row_begin = whole.row_begin + r0;
         b->vc.row_count = r1 - r0;
-        const int rc = launch(b, b->d_argb + offset, nullptr, b->stream);
+        const int rc = launch(b, b->d_argb + offset, nullptr, b->stream, own_scratch(b));
         b->vc = whole;
         if(rc != AEHIP_OK) {
             (void)hipStreamSynchronize(b->copy_stream);     // earlier parts' copies still write the staging buffer
@@ -2552,7 +2647,7 @@ int aehip_backend_stats(aehip_backend *b, aehip_stats *out) {
         b->stats.lane_slots = b->known_lane_slots;
     } else if(b->vc.flags & AEHIP_FLAG_COUNT_RAYS) {
         unsigned long long counters[2] = {0, 0};
-        AEHIP_CHECK(hipMemcpy(counters, b->d_rays, sizeof(counters), hipMemcpyDeviceToHost));
+        AEHIP_CHECK(hipMemcpy(counters, b->last_counters ? b->last_counters : b->d_rays, sizeof(counters), hipMemcpyDeviceToHost));
         b->stats.rays = counters[0];
         b->stats.lane_slots = counters[1];
     } else {
@@ -2717,7 +2812,7 @@ extern "C" int aehip_trace_frame(int n_devices, const aehip_scene *scene, const 
         aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
         AEHIP_CHECK(hipSetDevice(b->device));
         AEHIP_CHECK(hipEventRecord(b->ev_begin, b->stream));
-        const int rc = launch(b, b->d_argb, nullptr, b->stream);
+        const int rc = launch(b, b->d_argb, nullptr, b->stream, own_scratch(b));
         if(rc != AEHIP_OK) return rc;
         AEHIP_CHECK(hipEventRecord(b->ev_end, b->stream));
     }

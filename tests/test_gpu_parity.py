@@ -372,6 +372,56 @@ def test_streamed_exact_pass_equals_the_per_lane_pass_at_1080p():
     assert st_a.rays / st_a.lane_slots > 1.5 * st_b.rays / st_b.lane_slots
 
 
+def test_streamed_pass_in_several_windows_equals_the_per_lane_pass():
+    """The streamed pass keeps a block of per-path radiance for a window of strips, at most 448 MiB:
+    a 1080p band at 64 samples per pixel (32,400 strips of 49,920 bytes) takes four windows.  Same
+    bits as the one-lane-per-pixel pass, which needs no such buffer."""
+    import torch
+
+    sph = scenes.divergence_scene()
+    w, h = 1920, 1080
+    a_argb, a_rgba, st_a = render_device(w, h, spp=64, max_depth=5, seed=7, jitter=True, spheres=sph, count_rays=True)
+    back = rt.HipRaytracer(None)
+    try:
+        f = rt.FLAG_JITTER | rt.FLAG_COUNT_RAYS | rt.FLAG_NO_REGEN
+        assert back.setup(w, h, 64, 5, 7, f, rt.PASS_PATH, spheres=sph)
+        argb = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+        rgba = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        back.trace_device(argb.data_ptr(), rgba.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        st_b = back.stats()
+        np.testing.assert_array_equal(a_argb, argb.cpu().numpy().view(np.uint32))
+        np.testing.assert_array_equal(a_rgba.view(np.uint32), rgba.cpu().numpy().view(np.uint32))
+    finally:
+        back.close()
+    assert st_a.rays == st_b.rays
+
+
+def test_streamed_launches_on_two_streams_share_the_scratch_in_order():
+    """Launches of one backend on alternating streams (as bench.py and the frame pipeline issue
+    them) share its scratch: the library orders a launch that uses the scratch after the previous
+    one, so every frame equals the frame of a single launch."""
+    import torch
+
+    sph = scenes.divergence_scene()
+    w, h = 480, 270
+    want, _, st = render_device(w, h, want_rgba=False, spp=8, max_depth=30, seed=5, jitter=True, spheres=sph, count_rays=True)
+    back = rt.HipRaytracer(None)
+    try:
+        assert back.setup(w, h, 8, 30, 5, rt.FLAG_JITTER | rt.FLAG_COUNT_RAYS, rt.PASS_PATH, spheres=sph)
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        frames = [torch.zeros((h, w), dtype=torch.int32, device="cuda") for _ in range(6)]
+        torch.cuda.synchronize()
+        for i, frame in enumerate(frames):
+            back.trace_device(frame.data_ptr(), None, streams[i % 2].cuda_stream)
+        torch.cuda.synchronize()
+        for frame in frames:
+            np.testing.assert_array_equal(frame.cpu().numpy().view(np.uint32), want)
+        assert back.stats().rays == st.rays
+    finally:
+        back.close()
+
+
 @pytest.mark.parametrize("fast", [False, True], ids=["exact", "fast"])
 @pytest.mark.parametrize("size,spp", [((200, 120), 5), ((960, 540), 2)])
 def test_streamed_pass_with_first_hits_equals_the_per_lane_pass(size, spp, fast):
