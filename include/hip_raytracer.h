@@ -181,6 +181,15 @@ int aehip_backend_stats(aehip_backend *backend, aehip_stats *out);
 int aehip_trace_frame(int n_devices, const aehip_scene *scene, const aehip_params *params, uint32_t *framebuffer,
                       aehip_stats *stats);
 
+/* The band arithmetic of aehip_trace_frame on its own (no GPU needed): when `row_count` rows are cut
+ * into tiles of `tile_rows` rows (0 = 4, src/raytracer.h:28) dealt round-robin to `n_bands` bands,
+ * band `band` starts at row *first_row (relative to the frame's first row), holds *rows rows in
+ * tiles every n_bands * tile_rows rows, and its rows follow *rows_before rows of earlier bands in
+ * the densely stored gather buffer.  The reference's scheduler walks the same tiles one by one
+ * (src/software_raytracer.cpp:242-261). */
+int aehip_frame_band(uint32_t row_count, uint32_t tile_rows, int n_bands, int band, uint32_t *first_row, uint32_t *rows,
+                     uint32_t *rows_before);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,13 @@ def lib() -> ctypes.CDLL:
         L.orc_pcg_hash.restype = u32
         L.orc_path_key.argtypes = [u32, u32, u32]
         L.orc_path_key.restype = u32
+        L.orc_pixel_term.argtypes = [u32, u32]
+        L.orc_pixel_term.restype = u32
+        L.orc_sample_term.argtypes = [u32, u32]
+        L.orc_sample_term.restype = u32
+        L.orc_sample_offset.argtypes = [u32, u32, u32, f32p, f32p]
+        L.orc_sample_row_length_log2.argtypes = [u32]
+        L.orc_sample_row_length_log2.restype = u32
         L.orc_rng_next.argtypes = [u32p]
         L.orc_rng_next.restype = u32
         L.orc_cossin_2pi.argtypes = [ctypes.c_float, f32p, f32p]

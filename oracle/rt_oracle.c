@@ -159,9 +159,8 @@ void orc_trace_primary(const orc_scene *scene, uint32_t width, uint32_t height,
  *   sample_term = hash(sample + hash(seed) ^ 0x9e3779b9)   one pseudo-random word per sample
  *                                                          index, shared by all pixels;
  *   pixel_term  = hash(pixel  + hash(seed))                a pseudo-random rotation per pixel.
- * The two 16-bit halves of the key are the sub-pixel offsets, so every pixel sees the same
- * sample pattern under its own toroidal shift (a Cranley-Patterson rotation): unbiased, and the
- * per-sample cost on the GPU is one integer add. */
+ * The key seeds the path's generator (material scatter).  Where the samples of a pixel sit
+ * is a separate matter: orc_sample_offset below. */
 
 uint32_t orc_pcg_hash(uint32_t v) {
     const uint32_t s = v * 747796405u + 2891336453u;
@@ -179,6 +178,38 @@ uint32_t orc_pixel_term(uint32_t seed, uint32_t pixel_index) {
 
 uint32_t orc_path_key(uint32_t seed, uint32_t pixel_index, uint32_t sample_index) {
     return orc_pixel_term(seed, pixel_index) + orc_sample_term(seed, sample_index);
+}
+
+/* [spec] Sample positions inside a pixel: a grid of cells, one sample per cell, every cell's
+ * sample at the same place inside its cell -- the pixel's own random offset (rx, ry), the two
+ * halves of its pixel term.  Each sample is uniform over its cell, the cells tile the pixel, so
+ * the mean over samples is an unbiased estimate of the pixel's box-filtered value, with the
+ * variance of a stratified pattern.  Layout for spp samples: rows of nx = 2^floor(log2(spp)/2)
+ * cells (32 x 32 for 1024, 8 x 8 for 64); sample s sits in row r = s / nx, cell i = s % nx; a last
+ * row that is not full holds its n_r = spp - r nx cells at width 1/n_r; a row's height is its
+ * share n_r / spp of the samples.
+ *     jx = (i + rx) * (1 / n_r)            jy = (r nx + ry n_r) * (1 / spp)
+ * in binary32, the two reciprocals rounded once on the host (exact for powers of two).  On the
+ * GPU the cell index is the same in every lane, so a sample costs no hash, no integer-to-float
+ * conversion and no scalar-cache read: one vector add moves the ray to the next cell. */
+uint32_t orc_sample_row_length_log2(uint32_t spp) {
+    uint32_t bits = 0;
+    while((2u << bits) <= spp && bits < 31) bits++;        /* bits = floor(log2(spp)) */
+    return bits / 2;
+}
+
+void orc_sample_offset(uint32_t spp, uint32_t sample, uint32_t pixel_term, float *jx, float *jy) {
+    const uint32_t nxl = orc_sample_row_length_log2(spp);
+    const uint32_t nx = 1u << nxl;
+    const uint32_t r = sample >> nxl, i = sample & (nx - 1u);
+    const uint32_t left = spp - (r << nxl);
+    const uint32_t n_r = left < nx ? left : nx;
+    const float rx = (float)(pixel_term >> 16) * (1.0f / 65536.0f);
+    const float ry = (float)(pixel_term & 0xffffu) * (1.0f / 65536.0f);
+    const float inv_row = 1.0f / (float)n_r;
+    const float inv_spp = 1.0f / (float)spp;
+    *jx = ((float)i + rx) * inv_row;
+    *jy = ((float)(r << nxl) + ry * (float)n_r) * inv_spp;
 }
 
 /* The path's generator is PCG RXS-M-XS 32 proper: the state starts at the path key, every draw
@@ -256,10 +287,7 @@ static void trace_one_path(const orc_scene *scene, const view_t *v, const orc_pa
     uint32_t rng = key;
 
     float jx = 0.5f, jy = 0.5f;
-    if(p->flags & ORC_FLAG_JITTER) {
-        jx = (float)(key >> 16) * (1.0f / 65536.0f);
-        jy = (float)(key & 0xffffu) * (1.0f / 65536.0f);
-    }
+    if(p->flags & ORC_FLAG_JITTER) orc_sample_offset(p->spp, sample, orc_pixel_term(p->seed, y * v->width + x), &jx, &jy);
 
     v3 o = v->cam;
     v3 d = primary_direction(v, (float)x + jx, (float)y + jy);

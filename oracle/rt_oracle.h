@@ -86,6 +86,8 @@ uint32_t orc_sample_term(uint32_t seed, uint32_t sample_index);
 uint32_t orc_pixel_term(uint32_t seed, uint32_t pixel_index);
 uint32_t orc_path_key(uint32_t seed, uint32_t pixel_index, uint32_t sample_index);
 uint32_t orc_rng_next(uint32_t *state);
+uint32_t orc_sample_row_length_log2(uint32_t spp);
+void orc_sample_offset(uint32_t spp, uint32_t sample, uint32_t pixel_term, float *jx, float *jy);
 void orc_cossin_2pi(float u, float *out_cos, float *out_sin);
 void orc_unit_vector(uint32_t bits, float out[3]);
 

@@ -88,6 +88,7 @@ EXPORTS = (
     "aehip_backend_trace_device_static",
     "aehip_backend_stats",
     "aehip_trace_frame",
+    "aehip_frame_band",
 )
 
 
@@ -129,6 +130,7 @@ def load() -> ctypes.CDLL:
         L.aehip_backend_stats.argtypes = [vp, ctypes.POINTER(AehipStats)]
         L.aehip_trace_frame.argtypes = [ctypes.c_int, ctypes.POINTER(AehipScene), ctypes.POINTER(AehipParams), vp,
                                         ctypes.POINTER(AehipStats)]
+        L.aehip_frame_band.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int] + [ctypes.POINTER(ctypes.c_uint32)] * 3
         _lib = L
     return _lib
 

@@ -69,6 +69,8 @@ struct view_consts {
     uint32_t flags;
     uint32_t n_spheres;
     float list_centre[3];       // origin of the coordinates the list prefilter works in (see prefilter_entry)
+    uint32_t row_bits;          // a row of the pixel's sample grid has 2^row_bits cells (see sample_offset)
+    float inv_spp;              // 1.0f / spp, rounded once on the host
 };
 
 struct f3 {
@@ -199,6 +201,34 @@ __host__ __device__ __forceinline__ uint32_t sample_term(uint32_t seed_hash, uin
 __device__ __forceinline__ uint32_t rng_next(uint32_t &state) {
     state = state * 747796405u + 2891336453u;
     return pcg_permute(state);
+}
+
+// Where the samples of a pixel sit: one per cell of a grid over the pixel, every cell's sample at
+// the same place inside its cell -- the pixel's own offset (rx, ry), the halves of its pixel
+// term.  Each sample is uniform over its cell and the cells tile the pixel, so the mean is an
+// unbiased estimate of the pixel's box-filtered value with a stratified pattern's variance.
+// Rows of nx = 2^floor(log2(spp) / 2) cells (32 x 32 for 1024 samples); sample s is cell i = s % nx
+// of row r = s / nx; a last row that is not full holds its n_r cells at width 1 / n_r, and a row's
+// height is its share n_r / spp of the samples:
+//     jx = (i + rx) * (1 / n_r)            jy = (r nx + ry n_r) * (1 / spp)
+// The cell index is the same in every lane of a wave that walks a pixel block's samples together,
+// which is what the camera pass builds on: no hash, conversion or table read per sample.
+struct pixel_offset {
+    float rx, ry;
+};
+__device__ __forceinline__ pixel_offset offset_of_pixel(uint32_t pix_term) {
+    return pixel_offset{static_cast<float>(pix_term >> 16) * (1.0f / 65536.0f), static_cast<float>(pix_term & 0xffffu) * (1.0f / 65536.0f)};
+}
+__device__ __forceinline__ uint32_t cells_in_row(const view_consts &vc, uint32_t row) {
+    return min(1u << vc.row_bits, vc.spp - (row << vc.row_bits));
+}
+__device__ __forceinline__ void sample_offset(const view_consts &vc, uint32_t sample, uint32_t pix_term, float &jx, float &jy) {
+    const uint32_t r = sample >> vc.row_bits, i = sample & ((1u << vc.row_bits) - 1u);
+    const uint32_t n_r = cells_in_row(vc, r);
+    const pixel_offset o = offset_of_pixel(pix_term);
+    const float inv_row = 1.0f / static_cast<float>(n_r);          // correctly rounded (exact for a full row)
+    jx = (static_cast<float>(i) + o.rx) * inv_row;
+    jy = (static_cast<float>(r << vc.row_bits) + o.ry * static_cast<float>(n_r)) * vc.inv_spp;
 }
 
 // cos, sin of 2*pi*u, u in [0,1): octant reduction + Taylor polynomials on [0, pi/4], built from
@@ -395,10 +425,7 @@ __device__ __forceinline__ void start_path(const view_consts &vc, uint32_t pix_t
                                            uint32_t x, uint32_t y, uint32_t sample, path_state &ps) {
     const uint32_t key = pix_term + sample_terms[sample];
     float jx = 0.5f, jy = 0.5f;
-    if(vc.flags & AEHIP_FLAG_JITTER) {
-        jx = static_cast<float>(key >> 16) * (1.0f / 65536.0f);
-        jy = static_cast<float>(key & 0xffffu) * (1.0f / 65536.0f);
-    }
+    if(vc.flags & AEHIP_FLAG_JITTER) sample_offset(vc, sample, pix_term, jx, jy);
     ps.rng = key;
     ps.bounce = 0;
     ps.o = f3{vc.cam[0], vc.cam[1], vc.cam[2]};
@@ -1452,76 +1479,91 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
         __syncthreads();
     }
 
+    (void)sample_terms;     // every path of this pass ends at its first hit: no path ever draws a random number
     const f3 bg = row_background<EXACT>(vc, y);
     const uint32_t pix_term = pixel_term(vc.seed_hash, y * vc.width + x);
-    // sample position = base + draw * scale: (2^-16, +0) with jitter, (0, +0.5) without.
-    // Both products are exact, so the fused form rounds once, like multiply-then-add.
+    // Sample positions (see sample_offset): the pixel's samples sit on a grid, the cell index is
+    // the same in every lane, and a row of cells shares its vertical position.  So the sample loop
+    // runs row by row: what depends on the row (the ray's v coordinate and everything built from
+    // it) is worked out once per row, and going to the next cell is one vector add.
     const bool jitter = (vc.flags & AEHIP_FLAG_JITTER) != 0;
-    const float jscale = jitter ? (1.0f / 65536.0f) : 0.0f;
-    const float xb = static_cast<float>(x) + (jitter ? 0.0f : 0.5f);
-    const float yb = static_cast<float>(y) + (jitter ? 0.0f : 0.5f);
+    const pixel_offset off = offset_of_pixel(pix_term);
+    const float xf = static_cast<float>(x), yf = static_cast<float>(y);
     const float dz = 0.0f - cam.z;
-    // per-pixel terms of the sample position folded into one fma per coordinate
-    const float ux0 = __builtin_fmaf(xb, vc.psx, -(vc.vw_half + cam.x));
-    const float uy0 = __builtin_fmaf(yb, vc.psy, -(vc.vh_half + cam.y));
-    const float sx = jscale * vc.psx, sy = jscale * vc.psy;
     const float dz2 = dz * dz;
+    const uint32_t row_cells = 1u << vc.row_bits;
+    // the ray's viewport offsets of a sample at (jx, jy) in the pixel, folded into one fma per coordinate:
+    // u = ux0 + psx * jx, v = uy0 + psy * jy
+    const float ux0 = __builtin_fmaf(xf, vc.psx, -(vc.vw_half + cam.x));
+    const float uy0 = __builtin_fmaf(yf, vc.psy, -(vc.vh_half + cam.y));
 
-    // One sphere: the discriminant as a quadratic in the two 16-bit jitter draws (jx, jy) of the
-    // sample, the ray being (ux0 + sx*jx, uy0 + sy*jy, dz):
-    //   disc = jx*(pxx*jx + pxy*jy + px) + jy*(pyy*jy + py) + p0        5 fmas per sample
-    // (4 when the sphere's centre is on the camera axis, AXIAL: pxy is then 0).
-    // pxx, pxy, pyy are the same for every pixel; px, py, p0 belong to the pixel.  (The vector unit
-    // works the first three out, so they sit in vector registers; moved to scalar registers the
-    // frame measured 1.99 ms instead of 1.94.)  Every
-    // term of the expansion is at most a few times M = h*h + dd*(oc.oc + r*r), so this evaluation
-    // is, like the direct one, within a few dozen unit roundoffs of M of the real value.
-    float pxx = 0.0f, pxy = 0.0f, pyy = 0.0f, px = 0.0f, py = 0.0f, p0 = 0.0f;
-    if constexpr(ONE) {
-        pxx = cc.q_uu * (sx * sx);
-        pxy = cc.q_uv * (sx * sy);
-        pyy = cc.q_vv * (sy * sy);
-        px = sx * __builtin_fmaf(2.0f * cc.q_uu, ux0, __builtin_fmaf(cc.q_uv, uy0, cc.q_u));
-        py = sy * __builtin_fmaf(2.0f * cc.q_vv, uy0, __builtin_fmaf(cc.q_uv, ux0, cc.q_v));
-        const float h0 = __builtin_fmaf(uy0, cc.oc[1], __builtin_fmaf(ux0, cc.oc[0], dz * cc.oc[2]));
-        const float dd0 = __builtin_fmaf(uy0, uy0, __builtin_fmaf(ux0, ux0, dz2));
-        p0 = __builtin_fmaf(-dd0, cc.c, h0 * h0);
-        if constexpr(EXACT) {
-            // screening: add the margin times an upper bound of M over the pixel's jitter range
-            // (all terms taken positive at the corner of the pixel farthest from the axes)
-            const float ua = fmaxf(fabsf(ux0), fabsf(__builtin_fmaf(65535.0f, sx, ux0)));
-            const float va = fmaxf(fabsf(uy0), fabsf(__builtin_fmaf(65535.0f, sy, uy0)));
-            const float hmax = __builtin_fmaf(ua, fabsf(cc.oc[0]), __builtin_fmaf(va, fabsf(cc.oc[1]), fabsf(dz * cc.oc[2])));
-            const float ddmax = __builtin_fmaf(ua, ua, __builtin_fmaf(va, va, dz2));
-            const float mmax = __builtin_fmaf(ddmax, cc.magnitude, hmax * hmax);
-            p0 = __builtin_fmaf(kScreenMargin * 1.001f, mmax, p0);
-        }
+    // One sphere: the discriminant h*h - dd*c of the unnormalised ray (u, v, dz) is a quadratic in
+    // (u, v) with the coefficients of camera_consts; along a row of cells v is fixed and
+    //   disc(u) = u * (q_uu * u + B) + C,   B = q_uv v + q_u,   C = v (q_vv v + q_v) + q_0:
+    // two fmas per sample.  Every term of the expansion is at most a few times
+    // M = h*h + dd*(oc.oc + r*r), so this evaluation is, like the direct one, within a few dozen
+    // unit roundoffs of M of the real value.  The exact build screens with it: its constant term
+    // takes the margin times an upper bound of M over the pixel (all terms taken positive at the
+    // corner of the pixel farthest from the axes).
+    float screen_margin = 0.0f;
+    if constexpr(ONE && EXACT) {
+        const float ua = fmaxf(fabsf(ux0), fabsf(ux0 + vc.psx));
+        const float va = fmaxf(fabsf(uy0), fabsf(uy0 + vc.psy));
+        const float hmax = __builtin_fmaf(ua, fabsf(cc.oc[0]), __builtin_fmaf(va, fabsf(cc.oc[1]), fabsf(dz * cc.oc[2])));
+        const float ddmax = __builtin_fmaf(ua, ua, __builtin_fmaf(va, va, dz2));
+        screen_margin = (kScreenMargin * 1.001f) * __builtin_fmaf(ddmax, cc.magnitude, hmax * hmax);
     }
+
+    // a row of cells inside the sample range [s, s_end): which cells, and where they sit
+    struct cell_row {
+        uint32_t count;         // cells of the row inside the range
+        float first;            // index of the first of them, as a float
+        float inv_cells;        // 1 / cells in the whole row (exact for a full row)
+        float jy;               // vertical position of the row's samples in the pixel
+    };
+    auto row_at = [&](uint32_t s, uint32_t s_end) {
+        cell_row cr;
+        if(!jitter) {           // every sample at the pixel centre: one "row" for the whole range
+            cr.count = s_end - s;
+            cr.first = 0.0f;
+            cr.inv_cells = 0.0f;
+            cr.jy = 0.5f;
+            return cr;
+        }
+        const uint32_t r = s >> vc.row_bits, n_r = cells_in_row(vc, r);
+        cr.count = min(s_end, (r << vc.row_bits) + n_r) - s;
+        cr.first = static_cast<float>(s & (row_cells - 1u));
+        cr.inv_cells = 1.0f / static_cast<float>(n_r);
+        cr.jy = (static_cast<float>(r << vc.row_bits) + off.ry * static_cast<float>(n_r)) * vc.inv_spp;
+        return cr;
+    };
 
     f3 sum = {0.0f, 0.0f, 0.0f};
 
     if constexpr(EXACT) {
-        // the sample's ray exactly as the reference builds it (src/software_raytracer.cpp:218-221)
-        auto exact_draw = [&](uint32_t key) {
-            const float px = __builtin_fmaf(static_cast<float>(key >> 16), jscale, xb);
-            const float py = __builtin_fmaf(static_cast<float>(key & 0xffffu), jscale, yb);
-            const float uvx = px * vc.psx - vc.vw_half;
-            const float uvy = py * vc.psy - vc.vh_half;
-            return f3{uvx - cam.x, uvy - cam.y, dz};
-        };
-
         for(uint32_t first = 0; first < nblocks; first += split) {      // a round: `split` consecutive blocks
             const uint32_t blk = first + part;
             f3 block = {0.0f, 0.0f, 0.0f};
-            if(blk < nblocks) {
+            if(blk < nblocks && valid) {
                 const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
                 const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
-                uint32_t term = sample_terms[s0];
-                if(valid) {
-                    for(uint32_t sample = s0; sample < s1; sample++) {
-                        const uint32_t key = pix_term + term;
-                        term = sample_terms[sample + 1];        // next sample's term (table has one spare entry)
-
+                for(uint32_t s = s0; s < s1;) {
+                    const cell_row cr = row_at(s, s1);
+                    s += cr.count;
+                    // the row's part of the sample's ray exactly as the reference builds it
+                    // (src/software_raytracer.cpp:218-221), and of the folded screening ray
+                    const float py = yf + cr.jy;
+                    const float draw_y = (py * vc.psy - vc.vh_half) - cam.y;
+                    const float v = __builtin_fmaf(cr.jy, vc.psy, uy0);
+                    const float du = vc.psx * cr.inv_cells;
+                    const float u_first = __builtin_fmaf(jitter ? off.rx * cr.inv_cells : 0.5f, vc.psx, ux0);
+                    float qb = 0.0f, qc = 0.0f;
+                    if constexpr(ONE && FOLD) {
+                        qb = __builtin_fmaf(cc.q_uv, v, cc.q_u);
+                        qc = __builtin_fmaf(v, __builtin_fmaf(cc.q_vv, v, cc.q_v), cc.q_0) + screen_margin;
+                    }
+                    float cell = cr.first;
+                    for(uint32_t k = 0; k < cr.count; k++, cell += 1.0f) {
                         // Conservative miss test on the unnormalised ray in fused arithmetic.  With
                         // h = draw.oc and dd = draw.draw the reference's discriminant has the sign of
                         // h*h - dd*c.  Both evaluations are within about a dozen unit roundoffs of
@@ -1529,41 +1571,42 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                         // negative in the exact evaluation as well, and the sample takes the row
                         // background whatever its direction is.  Everything else runs the exact
                         // arithmetic below.  Where the camera is not close to the viewport plane (host
-                        // check, kFlagFoldScreen) the screening ray comes from two fmas instead of the
-                        // reference's six operations: it differs from the exact ray by a few ulps of the
+                        // check, kFlagFoldScreen) the screening ray comes from fmas instead of the
+                        // reference's operations: it differs from the exact ray by a few ulps of the
                         // viewport extent, which moves the screening value by under 6e-6 of the
                         // magnitude -- inside the margin with room to spare.
-                        // One sphere, folded ray: the screening value is the pixel's quadratic in
-                        // the two jitter draws, margin included in its constant term.
+                        auto exact_draw = [&]() {
+                            const float jx = jitter ? (cell + off.rx) * cr.inv_cells : 0.5f;
+                            const float px = xf + jx;
+                            return f3{(px * vc.psx - vc.vw_half) - cam.x, draw_y, dz};
+                        };
                         f3 draw = {0.0f, 0.0f, dz};
                         bool maybe = false;
                         if constexpr(ONE && FOLD) {
-                            const float jx = static_cast<float>(key >> 16), jy = static_cast<float>(key & 0xffffu);
-                            const float t1 = AXIAL ? __builtin_fmaf(pxx, jx, px) : __builtin_fmaf(pxx, jx, __builtin_fmaf(pxy, jy, px));
-                            const float t2 = __builtin_fmaf(pyy, jy, py);
-                            maybe = __builtin_fmaf(jx, t1, __builtin_fmaf(jy, t2, p0)) >= 0.0f;
+                            const float u = __builtin_fmaf(cell, du, u_first);
+                            maybe = __builtin_fmaf(u, __builtin_fmaf(cc.q_uu, u, qb), qc) >= 0.0f;
                         } else {
                             float rx, ry;
                             if constexpr(FOLD) {
-                                rx = __builtin_fmaf(static_cast<float>(key >> 16), sx, ux0);
-                                ry = __builtin_fmaf(static_cast<float>(key & 0xffffu), sy, uy0);
+                                rx = __builtin_fmaf(cell, du, u_first);
+                                ry = v;
                             } else {
-                                draw = exact_draw(key);
+                                draw = exact_draw();
                                 rx = draw.x;
                                 ry = draw.y;
                             }
                             const float dd = __builtin_fmaf(ry, ry, __builtin_fmaf(rx, rx, dz2));
                             for(uint32_t i = 0; i < n_spheres; i++) {
-                                const float4 k = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
+                                const float4 kk = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
                                 const float mag = ONE ? cc.magnitude : s_ctr[i].w;
-                                const float h = __builtin_fmaf(ry, k.y, __builtin_fmaf(rx, k.x, dz * k.z));
+                                const float h = __builtin_fmaf(ry, kk.y, __builtin_fmaf(rx, kk.x, dz * kk.z));
                                 const float q = h * h;
-                                const float screen = __builtin_fmaf(kScreenMargin, __builtin_fmaf(dd, mag, q), __builtin_fmaf(-dd, k.w, q));
+                                const float screen = __builtin_fmaf(kScreenMargin, __builtin_fmaf(dd, mag, q), __builtin_fmaf(-dd, kk.w, q));
                                 maybe = maybe || (screen >= 0.0f);
                             }
                         }
                         if constexpr(FOLD) {
-                            if(maybe) draw = exact_draw(key);
+                            if(maybe) draw = exact_draw();
                         }
 
                         f3 L = bg;
@@ -1575,9 +1618,9 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                             float closest = 3.402823466e+38f;
                             int hit = -1;
                             for(uint32_t i = 0; i < n_spheres; i++) {
-                                const float4 k = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
-                                const float b = -2.0f * dot3<true>(d, f3{k.x, k.y, k.z});
-                                const float disc = b * b - a4 * k.w;
+                                const float4 kk = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
+                                const float b = -2.0f * dot3<true>(d, f3{kk.x, kk.y, kk.z});
+                                const float disc = b * b - a4 * kk.w;
                                 if(disc >= 0.0f) {
                                     // FAST_AFTER_DISC: up to here the sample is the reference's, bit for
                                     // bit (ray, normalisation, discriminant -- where its rounding is
@@ -1604,10 +1647,10 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                                 const f3 ctr = ONE ? f3{cc.center[0], cc.center[1], cc.center[2]}
                                                    : f3{s_ctr[hit].x, s_ctr[hit].y, s_ctr[hit].z};
                                 if constexpr(FAST_AFTER_DISC) {
-                                    const f3 v = {__builtin_fmaf(d.x, closest, cam.x - ctr.x), __builtin_fmaf(d.y, closest, cam.y - ctr.y),
+                                    const f3 w = {__builtin_fmaf(d.x, closest, cam.x - ctr.x), __builtin_fmaf(d.y, closest, cam.y - ctr.y),
                                                   __builtin_fmaf(d.z, closest, cam.z - ctr.z)};
-                                    const float half_inv = 0.5f * __builtin_amdgcn_rsqf(dot3<false>(v, v));
-                                    L = f3{__builtin_fmaf(v.x, half_inv, 0.5f), __builtin_fmaf(v.y, half_inv, 0.5f), __builtin_fmaf(v.z, half_inv, 0.5f)};
+                                    const float half_inv = 0.5f * __builtin_amdgcn_rsqf(dot3<false>(w, w));
+                                    L = f3{__builtin_fmaf(w.x, half_inv, 0.5f), __builtin_fmaf(w.y, half_inv, 0.5f), __builtin_fmaf(w.z, half_inv, 0.5f)};
                                 } else {
                                     const f3 pt = {d.x * closest + cam.x, d.y * closest + cam.y, d.z * closest + cam.z};
                                     const f3 n = normalize3<true>(f3{pt.x - ctr.x, pt.y - ctr.y, pt.z - ctr.z});
@@ -1651,25 +1694,28 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
         for(uint32_t blk = part; blk < nblocks; blk += split) {
             const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
             const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
-            uint32_t term = sample_terms[s0];
-            if(valid) {
-                // unrolled: with 8 vector instructions per missing sample the loop's own scalar
-                // instructions (counter, address, compare, branch) are what limits issue
+            if(!valid) continue;
+            for(uint32_t s = s0; s < s1;) {
+                const cell_row cr = row_at(s, s1);
+                s += cr.count;
+                const float v = __builtin_fmaf(cr.jy, vc.psy, uy0);
+                const float du = jitter ? vc.psx * cr.inv_cells : 0.0f;
+                // u of the cell before the row's first: the loop steps before it tests
+                float u = __builtin_fmaf(jitter ? (cr.first + off.rx) * cr.inv_cells : 0.5f, vc.psx, ux0) - du;
+                if constexpr(ONE) {
+                    const float qb = __builtin_fmaf(cc.q_uv, v, cc.q_u);
+                    const float qc = __builtin_fmaf(v, __builtin_fmaf(cc.q_vv, v, cc.q_v), cc.q_0);
+                    const float h_row = __builtin_fmaf(v, cc.oc[1], dz * cc.oc[2]);       // h = u oc.x + h_row
+                    const float dd_row = __builtin_fmaf(v, v, dz2);                      // dd = u u + dd_row
+                    float row_scale = 0.0f;
+                    // a missing sample is four vector instructions: step, two fmas, compare
 #pragma unroll 4
-                for(uint32_t sample = s0; sample < s1; sample++) {
-                    const uint32_t key = pix_term + term;
-                    term = sample_terms[sample + 1];        // next sample's term (table has one spare entry)
-                    const float jx = static_cast<float>(key >> 16), jy = static_cast<float>(key & 0xffffu);
-                    if constexpr(ONE) {
-                        // most samples miss: decide that from the pixel's quadratic before anything else
-                        const float t1 = AXIAL ? __builtin_fmaf(pxx, jx, px) : __builtin_fmaf(pxx, jx, __builtin_fmaf(pxy, jy, px));
-                        const float t2 = __builtin_fmaf(pyy, jy, py);
-                        const float disc = __builtin_fmaf(jx, t1, __builtin_fmaf(jy, t2, p0));
+                    for(uint32_t k = 0; k < cr.count; k++) {
+                        u += du;
+                        const float disc = __builtin_fmaf(u, __builtin_fmaf(cc.q_uu, u, qb), qc);
                         if(disc >= 0.0f) {
-                            const float dx = __builtin_fmaf(jx, sx, ux0);
-                            const float dy = __builtin_fmaf(jy, sy, uy0);
-                            const float dd = __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, dz2));
-                            const float h = __builtin_fmaf(dy, cc.oc[1], __builtin_fmaf(dx, cc.oc[0], dz * cc.oc[2]));
+                            const float dd = __builtin_fmaf(u, u, dd_row);
+                            const float h = __builtin_fmaf(u, cc.oc[0], h_row);
                             // The hit is at draw * t, t = root / dd, root = h -+ sqrt(disc); it lies
                             // beyond t_min when root > 0 and root*root > t_min^2 * dd.  With the
                             // camera outside the sphere by more than t_min (near_root_only) the two
@@ -1677,8 +1723,9 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                             // A point of the sphere is a radius away from the centre, so the
                             // normal is (draw*t - oc) / r without a normalisation, and its colour
                             // 0.5*n + 0.5 = draw * (0.5 t / r) + (0.5 - 0.5 oc / r).  The sum over
-                            // the pixel's hits needs only sum(dx*s), sum(dy*s), sum(s) with
-                            // s = 0.5 t / r; the constant parts are added once, below.
+                            // the pixel's hits needs only sum(u*s), sum(v*s), sum(s) with
+                            // s = 0.5 t / r (v and dz leave the sums of a row and of the pixel); the
+                            // constant parts are added once, below.
                             const float sq = __builtin_amdgcn_sqrtf(disc);
                             float root = h - sq;
                             bool ok;
@@ -1691,49 +1738,51 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                             }
                             if(ok) {
                                 const float sc = (root * cc.shade_scale) * __builtin_amdgcn_rcpf(dd);
-                                sum.x = __builtin_fmaf(dx, sc, sum.x);
-                                sum.y = __builtin_fmaf(dy, sc, sum.y);
-                                sum.z += sc;
+                                sum.x = __builtin_fmaf(u, sc, sum.x);
+                                row_scale += sc;
                                 hits++;
                             }
                         }
-                        continue;
                     }
-                    const float dx = __builtin_fmaf(jx, sx, ux0);
-                    const float dy = __builtin_fmaf(jy, sy, uy0);
-                    const float dd = __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, dz2));
-                    float closest = 3.402823466e+38f;
-                    int hit = -1;
-                    for(uint32_t i = 0; i < n_spheres; i++) {
-                        const float4 k = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
-                        const float h = __builtin_fmaf(dy, k.y, __builtin_fmaf(dx, k.x, dz * k.z));
-                        const float disc = __builtin_fmaf(-dd, k.w, h * h);
-                        if(disc >= 0.0f) {
-                            const float sq = __builtin_amdgcn_sqrtf(disc);
-                            const float inv = __builtin_amdgcn_rcpf(dd);
-                            const float tmin = kTMin * __builtin_amdgcn_rsqf(dd);       // t_min in units of |draw|
-                            float t = (h - sq) * inv;
-                            bool ok = (t > tmin) && (t < closest);
-                            if(!ok) {
-                                t = (h + sq) * inv;
-                                ok = (t > tmin) && (t < closest);
-                            }
-                            if(ok) {
-                                closest = t;
-                                hit = static_cast<int>(i);
+                    sum.y = __builtin_fmaf(v, row_scale, sum.y);
+                    sum.z += row_scale;
+                } else {
+                    const float dd_row = __builtin_fmaf(v, v, dz2);
+                    for(uint32_t k = 0; k < cr.count; k++) {
+                        u += du;
+                        const float dd = __builtin_fmaf(u, u, dd_row);
+                        float closest = 3.402823466e+38f;
+                        int hit = -1;
+                        for(uint32_t i = 0; i < n_spheres; i++) {
+                            const float4 kk = s_occ[i];
+                            const float h = __builtin_fmaf(v, kk.y, __builtin_fmaf(u, kk.x, dz * kk.z));
+                            const float disc = __builtin_fmaf(-dd, kk.w, h * h);
+                            if(disc >= 0.0f) {
+                                const float sq = __builtin_amdgcn_sqrtf(disc);
+                                const float inv = __builtin_amdgcn_rcpf(dd);
+                                const float tmin = kTMin * __builtin_amdgcn_rsqf(dd);       // t_min in units of |draw|
+                                float t = (h - sq) * inv;
+                                bool ok = (t > tmin) && (t < closest);
+                                if(!ok) {
+                                    t = (h + sq) * inv;
+                                    ok = (t > tmin) && (t < closest);
+                                }
+                                if(ok) {
+                                    closest = t;
+                                    hit = static_cast<int>(i);
+                                }
                             }
                         }
-                    }
-                    if(hit >= 0) {
-                        const f3 ctr = ONE ? f3{cc.center[0], cc.center[1], cc.center[2]}
-                                           : f3{s_ctr[hit].x, s_ctr[hit].y, s_ctr[hit].z};
-                        const f3 v = {__builtin_fmaf(dx, closest, cam.x - ctr.x), __builtin_fmaf(dy, closest, cam.y - ctr.y),
-                                      __builtin_fmaf(dz, closest, cam.z - ctr.z)};
-                        const float half_inv = 0.5f * __builtin_amdgcn_rsqf(dot3<false>(v, v));
-                        sum.x += __builtin_fmaf(v.x, half_inv, 0.5f);
-                        sum.y += __builtin_fmaf(v.y, half_inv, 0.5f);
-                        sum.z += __builtin_fmaf(v.z, half_inv, 0.5f);
-                        hits++;
+                        if(hit >= 0) {
+                            const f3 ctr = {s_ctr[hit].x, s_ctr[hit].y, s_ctr[hit].z};
+                            const f3 w = {__builtin_fmaf(u, closest, cam.x - ctr.x), __builtin_fmaf(v, closest, cam.y - ctr.y),
+                                          __builtin_fmaf(dz, closest, cam.z - ctr.z)};
+                            const float half_inv = 0.5f * __builtin_amdgcn_rsqf(dot3<false>(w, w));
+                            sum.x += __builtin_fmaf(w.x, half_inv, 0.5f);
+                            sum.y += __builtin_fmaf(w.y, half_inv, 0.5f);
+                            sum.z += __builtin_fmaf(w.z, half_inv, 0.5f);
+                            hits++;
+                        }
                     }
                 }
             }
@@ -1914,6 +1963,7 @@ struct aehip_backend {
     bool wants_streamed_pass = false;        // the request goes through the streamed pass (decided by set-up)
     hipEvent_t ev_scratch = nullptr;         // end of the last launch that used the scratch or the counters
     unsigned long long *last_counters = nullptr;     // where the last launch counted rays (own or static scratch)
+    uint64_t setup_digest = 0;               // aehip_trace_frame: digest of the scene and request of the last set-up
 
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;       // device -> host copies of finished parts of a frame (aehip_backend_trace)
@@ -2322,6 +2372,12 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
     vc.spp = p.spp;
     vc.max_depth = p.max_depth;
     vc.seed_hash = pcg_hash(p.seed);
+    {
+        uint32_t bits = 0;
+        while((2u << bits) <= p.spp && bits < 31) bits++;       // floor(log2(spp))
+        vc.row_bits = bits / 2;
+        vc.inv_spp = 1.0f / static_cast<float>(p.spp);
+    }
     vc.flags = p.flags & ~kFlagFoldScreen;
     {
         // The folded screening ray is off from the exact one by a few ulps of the viewport extent
@@ -2722,6 +2778,30 @@ int load_rccl(rccl_api &api) {
 
 }  // namespace
 
+// Band i of n when the frame's rows are cut into tiles of tile_rows rows dealt round-robin: which
+// rows it has and where its rows start among the densely stored bands (band order).
+extern "C" int aehip_frame_band(uint32_t row_count, uint32_t tile_rows, int n_bands, int band, uint32_t *first_row,
+                                uint32_t *rows, uint32_t *rows_before) {
+    if(n_bands < 1 || band < 0 || band >= n_bands || !first_row || !rows || !rows_before) return fail(AEHIP_E_INVALID, "aehip_frame_band: bad argument");
+    const uint32_t T = tile_rows ? tile_rows : 4u;
+    const uint32_t tiles = (row_count + T - 1) / T;
+    if(static_cast<uint32_t>(n_bands) > tiles) return fail(AEHIP_E_INVALID, "%d devices for %u tiles of %u rows", n_bands, tiles, T);
+    const uint32_t stride = static_cast<uint32_t>(n_bands) * T;
+    uint32_t before = 0;
+    for(int i = 0; i <= band; i++) {
+        const uint32_t span = row_count - static_cast<uint32_t>(i) * T;
+        const uint32_t whole = span / stride, rest = span % stride;
+        const uint32_t mine = whole * T + (rest < T ? rest : T);
+        if(i == band) {
+            *first_row = static_cast<uint32_t>(i) * T;
+            *rows = mine;
+            *rows_before = before;
+        }
+        before += mine;
+    }
+    return AEHIP_OK;
+}
+
 extern "C" int aehip_trace_frame(int n_devices, const aehip_scene *scene, const aehip_params *params,
                                  uint32_t *framebuffer, aehip_stats *stats_out) {
     if(!scene || !params || !framebuffer) return fail(AEHIP_E_INVALID, "aehip_trace_frame: null argument");
@@ -2759,29 +2839,50 @@ extern "C" int aehip_trace_frame(int n_devices, const aehip_scene *scene, const 
         if(rc != AEHIP_OK) return rc;
         for(ncclComm_t c : g_frame.comms)
             if(c) (void)g_frame.rccl.CommDestroy(c);
-        g_frame.comms.assign(static_cast<size_t>(n), nullptr);
+        g_frame.comms.clear();
+        // into a local vector first: a failed initialisation must not leave null communicators behind
+        std::vector<ncclComm_t> fresh(static_cast<size_t>(n), nullptr);
         std::vector<int> devs(static_cast<size_t>(n));
         for(int i = 0; i < n; i++) devs[static_cast<size_t>(i)] = i;
-        AEHIP_RCCL_CHECK(g_frame.rccl, g_frame.rccl.CommInitAll(g_frame.comms.data(), n, devs.data()));
+        AEHIP_RCCL_CHECK(g_frame.rccl, g_frame.rccl.CommInitAll(fresh.data(), n, devs.data()));
+        g_frame.comms.swap(fresh);
     }
 
     std::vector<uint32_t> band_rows(static_cast<size_t>(n)), offset(static_cast<size_t>(n) + 1, 0u);   // in rows
     const uint32_t stride = static_cast<uint32_t>(n) * T;
     for(int i = 0; i < n; i++) {
-        const uint32_t span = frame.row_count - static_cast<uint32_t>(i) * T;
-        const uint32_t whole = span / stride, rest = span % stride;
-        band_rows[static_cast<size_t>(i)] = whole * T + (rest < T ? rest : T);
+        uint32_t first_row = 0;
+        const int rc = aehip_frame_band(frame.row_count, T, n, i, &first_row, &band_rows[static_cast<size_t>(i)], &offset[static_cast<size_t>(i)]);
+        if(rc != AEHIP_OK) return rc;
         offset[static_cast<size_t>(i) + 1] = offset[static_cast<size_t>(i)] + band_rows[static_cast<size_t>(i)];
     }
 
+    // Set-up (scene upload, tables, a synchronisation each) only when the scene or the request
+    // changed since the band's last frame: a caller that renders frame after frame pays it once.
+    uint64_t digest = 1469598103934665603ull;
+    auto mix = [&digest](const void *data, size_t bytes) {
+        const unsigned char *p = static_cast<const unsigned char *>(data);
+        for(size_t k = 0; k < bytes; k++) digest = (digest ^ p[k]) * 1099511628211ull;
+    };
+    mix(&frame, sizeof(frame));
+    mix(scene->background0, sizeof(scene->background0));
+    mix(scene->background1, sizeof(scene->background1));
+    mix(scene->camera_pos, sizeof(scene->camera_pos));
+    mix(&scene->sphere_count, sizeof(scene->sphere_count));
+    if(scene->spheres) mix(scene->spheres, sizeof(aehip_sphere) * scene->sphere_count);
+    mix(&n, sizeof(n));
     for(int i = 0; i < n; i++) {
+        aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
+        if(b->ready && b->setup_digest == digest) continue;
         aehip_params p = frame;
         p.row_begin = frame.row_begin + static_cast<uint32_t>(i) * T;
         p.row_count = band_rows[static_cast<size_t>(i)];
         p.tile_rows = n > 1 ? T : 0u;
         p.tile_stride = n > 1 ? stride : 0u;
-        const int rc = aehip_backend_setup(g_frame.bands[static_cast<size_t>(i)], scene, &p);
+        b->setup_digest = 0;
+        const int rc = aehip_backend_setup(b, scene, &p);
         if(rc != AEHIP_OK) return rc;
+        b->setup_digest = digest;
     }
 
     // device 0 holds every band, densely, one after the other, and renders its own band straight
@@ -2807,50 +2908,72 @@ extern "C" int aehip_trace_frame(int n_devices, const aehip_scene *scene, const 
         b0->staging_capacity = frame_pixels;
     }
 
+    // From the first launch on, an error must not return while other devices still work on buffers
+    // a later call may free: wait for every band's stream, then report.
+    auto settle = [&](int rc) {
+        for(int i = 0; i < n; i++) {
+            aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
+            if(hipSetDevice(b->device) == hipSuccess) (void)hipStreamSynchronize(b->stream);
+        }
+        return rc;
+    };
+#define AEHIP_FRAME_CHECK(expr)                                                                                     \
+    do {                                                                                                            \
+        hipError_t e_ = (expr);                                                                                     \
+        if(e_ != hipSuccess) return settle(fail(AEHIP_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)));       \
+    } while(0)
+#define AEHIP_FRAME_RCCL_CHECK(api, expr)                                                                           \
+    do {                                                                                                            \
+        ncclResult_t r_ = (expr);                                                                                   \
+        if(r_ != ncclSuccess) return settle(fail(AEHIP_E_HIP, "%s failed: %s", #expr, (api).GetErrorString(r_)));   \
+    } while(0)
+
     // render: every device at once, each on its own stream
     for(int i = 0; i < n; i++) {
         aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
-        AEHIP_CHECK(hipSetDevice(b->device));
-        AEHIP_CHECK(hipEventRecord(b->ev_begin, b->stream));
+        AEHIP_FRAME_CHECK(hipSetDevice(b->device));
+        AEHIP_FRAME_CHECK(hipEventRecord(b->ev_begin, b->stream));
         const int rc = launch(b, b->d_argb, nullptr, b->stream, own_scratch(b));
-        if(rc != AEHIP_OK) return rc;
-        AEHIP_CHECK(hipEventRecord(b->ev_end, b->stream));
+        if(rc != AEHIP_OK) return settle(rc);
+        AEHIP_FRAME_CHECK(hipEventRecord(b->ev_end, b->stream));
     }
 
-    // gather the peers' bands into device 0's frame
+    // gather the peers' bands into device 0's frame.  Nothing here waits on the host: the RCCL
+    // receives are ordered on device 0's stream, and a device-to-device copy (bands that share
+    // device 0's GPU) ends in an event that device 0's stream waits on.
     if(n > 1 && distinct) {
         rccl_api &api = g_frame.rccl;
-        AEHIP_RCCL_CHECK(api, api.GroupStart());
+        AEHIP_FRAME_RCCL_CHECK(api, api.GroupStart());
         for(int i = 1; i < n; i++) {
             aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
             const size_t count = static_cast<size_t>(frame.width) * b->vc.row_count;
-            AEHIP_CHECK(hipSetDevice(b->device));
-            AEHIP_RCCL_CHECK(api, api.Send(b->d_argb, count, ncclUint32, 0, g_frame.comms[static_cast<size_t>(i)], b->stream));
-            AEHIP_CHECK(hipSetDevice(b0->device));
-            AEHIP_RCCL_CHECK(api, api.Recv(b0->d_argb + static_cast<size_t>(frame.width) * offset[static_cast<size_t>(i)], count, ncclUint32, i,
-                                           g_frame.comms[0], b0->stream));
+            AEHIP_FRAME_CHECK(hipSetDevice(b->device));
+            AEHIP_FRAME_RCCL_CHECK(api, api.Send(b->d_argb, count, ncclUint32, 0, g_frame.comms[static_cast<size_t>(i)], b->stream));
+            AEHIP_FRAME_CHECK(hipSetDevice(b0->device));
+            AEHIP_FRAME_RCCL_CHECK(api, api.Recv(b0->d_argb + static_cast<size_t>(frame.width) * offset[static_cast<size_t>(i)], count, ncclUint32, i,
+                                                 g_frame.comms[0], b0->stream));
         }
-        AEHIP_RCCL_CHECK(api, api.GroupEnd());
+        AEHIP_FRAME_RCCL_CHECK(api, api.GroupEnd());
     } else if(n > 1) {
         for(int i = 1; i < n; i++) {
             aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
             const size_t bytes = static_cast<size_t>(frame.width) * b->vc.row_count * sizeof(uint32_t);
-            AEHIP_CHECK(hipSetDevice(b->device));
-            AEHIP_CHECK(hipMemcpyPeerAsync(b0->d_argb + static_cast<size_t>(frame.width) * offset[static_cast<size_t>(i)], b0->device,
-                                           b->d_argb, b->device, bytes, b->stream));
+            AEHIP_FRAME_CHECK(hipSetDevice(b->device));
+            AEHIP_FRAME_CHECK(hipMemcpyPeerAsync(b0->d_argb + static_cast<size_t>(frame.width) * offset[static_cast<size_t>(i)], b0->device,
+                                                 b->d_argb, b->device, bytes, b->stream));
+            AEHIP_FRAME_CHECK(hipEventRecord(b->ev_copy, b->stream));
+            AEHIP_FRAME_CHECK(hipSetDevice(b0->device));
+            AEHIP_FRAME_CHECK(hipStreamWaitEvent(b0->stream, b->ev_copy, 0));
         }
-    }
-    for(int i = 1; i < n; i++) {
-        aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
-        AEHIP_CHECK(hipSetDevice(b->device));
-        AEHIP_CHECK(hipStreamSynchronize(b->stream));
     }
 
     // bands -> pinned staging
-    AEHIP_CHECK(hipSetDevice(b0->device));
-    AEHIP_CHECK(hipMemcpyAsync(b0->h_staging, b0->d_argb, frame_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, b0->stream));
-    AEHIP_CHECK(hipEventRecord(b0->ev_copy, b0->stream));
-    AEHIP_CHECK(hipStreamSynchronize(b0->stream));
+    AEHIP_FRAME_CHECK(hipSetDevice(b0->device));
+    AEHIP_FRAME_CHECK(hipMemcpyAsync(b0->h_staging, b0->d_argb, frame_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, b0->stream));
+    AEHIP_FRAME_CHECK(hipEventRecord(b0->ev_copy, b0->stream));
+    AEHIP_FRAME_CHECK(hipStreamSynchronize(b0->stream));
+#undef AEHIP_FRAME_CHECK
+#undef AEHIP_FRAME_RCCL_CHECK
     // pinned staging (band order) -> caller's buffer (image order), one copy per tile
     for(int i = 0; i < n; i++) {
         const uint32_t rows = band_rows[static_cast<size_t>(i)];

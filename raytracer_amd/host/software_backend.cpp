@@ -113,6 +113,7 @@ struct view {
     u32 pixel_rotation, sample_rotation;     // hash(seed), hash(seed) ^ golden ratio
     bool jitter;
     u32 depth;
+    u32 spp, row_bits;          // samples per pixel; a row of the sample grid has 2^row_bits cells
 };
 
 // src/software_raytracer.cpp:218-221 + src/ray.h:18-20
@@ -134,8 +135,18 @@ vec3 follow_path(const view &v, const std::vector<aehip_sphere> &spheres, u32 x,
     stream draws{key};
     f32 jx = 0.5f, jy = 0.5f;
     if(v.jitter) {
-        jx = static_cast<f32>(key >> 16) * (1.0f / 65536.0f);
-        jy = static_cast<f32>(key & 0xffffu) * (1.0f / 65536.0f);
+        // One sample per cell of a grid over the pixel (rows of 2^row_bits cells, a shorter last
+        // row at its own cell width, row heights in proportion to their sample counts), every
+        // sample at the pixel's own offset inside its cell: the halves of the pixel's hash.
+        const u32 pixel_word = hash(y * v.width + x + v.pixel_rotation);
+        const u32 row_cells = 1u << v.row_bits;
+        const u32 row = sample >> v.row_bits, cell = sample & (row_cells - 1u);
+        const u32 left = v.spp - (row << v.row_bits);
+        const u32 in_row = left < row_cells ? left : row_cells;
+        const f32 ox = static_cast<f32>(pixel_word >> 16) * (1.0f / 65536.0f);
+        const f32 oy = static_cast<f32>(pixel_word & 0xffffu) * (1.0f / 65536.0f);
+        jx = (static_cast<f32>(cell) + ox) * (1.0f / static_cast<f32>(in_row));
+        jy = (static_cast<f32>(row << v.row_bits) + oy * static_cast<f32>(in_row)) * (1.0f / static_cast<f32>(v.spp));
     }
     vec3 origin = v.eye;
     vec3 dir = camera_ray(v, static_cast<f32>(x) + jx, static_cast<f32>(y) + jy);
@@ -288,6 +299,10 @@ void software_raytracer::trace_rows(u32 row_begin, u32 row_end, u64 &rays) const
     v.sample_rotation = hash(seed_) ^ 0x9e3779b9u;
     v.jitter = jitter_;
     v.depth = depth_;
+    v.spp = spp_;
+    u32 bits = 0;
+    while((2u << bits) <= spp_ && bits < 31) bits++;
+    v.row_bits = bits / 2;      // 2^floor(log2(spp) / 2) cells a row: 32 x 32 for 1024 samples
 
     for(u32 y = row_begin; y < row_end; y++) {
         u32 *out = framebuffer_ + static_cast<size_t>(y) * width_;

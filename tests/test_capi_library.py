@@ -76,3 +76,30 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(raytracer_amd, "LIB_PATH", "/nonexistent/libhip_raytracer.so")
     with pytest.raises(raytracer_amd.HipRaytracerError):
         raytracer_amd.load()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize("rows,tile", [(2160, 4), (1080, 4), (75, 7), (41, 16), (64, 1), (130, 5)])
+def test_frame_band_arithmetic_equals_the_python_sharding(n, rows, tile):
+    """aehip_frame_band (the band layout aehip_trace_frame renders and gathers by) against
+    raytracer_amd.sharding.tiled_band, which bench.py's ranks use: same first row, same row count,
+    bands stored densely in band order, every image row in exactly one band.  No GPU involved."""
+    import ctypes
+
+    from raytracer_amd.sharding import band_image_rows, tiled_band
+
+    L = raytracer_amd.load()
+    if n > -(-rows // tile):
+        first, count, before = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        assert L.aehip_frame_band(rows, tile, n, 0, ctypes.byref(first), ctypes.byref(count), ctypes.byref(before)) != 0
+        return
+    seen, expect_before = [], 0
+    for band in range(n):
+        first, count, before = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        assert L.aehip_frame_band(rows, tile, n, band, ctypes.byref(first), ctypes.byref(count), ctypes.byref(before)) == 0
+        want = tiled_band(rows, n, band, tile) if n > 1 else dict(row_begin=0, row_count=rows, tile_rows=0, tile_stride=0)
+        assert (first.value, count.value) == (want["row_begin"], want["row_count"])
+        assert before.value == expect_before
+        expect_before += count.value
+        seen += band_image_rows(dict(row_begin=first.value, row_count=count.value, tile_rows=tile if n > 1 else 0, tile_stride=tile * n))
+    assert sorted(seen) == list(range(rows))

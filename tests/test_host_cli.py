@@ -112,7 +112,8 @@ def test_cli_software_backend_is_independent_of_the_thread_count(tmp_path, threa
     ("divergence", ["--spp", "2", "--depth", "50", "--seed", "7", "--jitter"]),
     ("showcase", ["--spp", "70", "--depth", "3", "--seed", "11"]),
     (None, ["--spp", "8", "--depth", "8", "--seed", "1", "--jitter"]),
-], ids=["materials", "depth50", "two_sample_blocks_centred", "default_scene_jittered"])
+    ("showcase", ["--spp", "70", "--depth", "4", "--seed", "5", "--jitter"]),
+], ids=["materials", "depth50", "two_sample_blocks_centred", "default_scene_jittered", "two_blocks_partial_grid_row"])
 def test_cli_software_backend_extended_model_matches_oracle(tmp_path, scene, args):
     """Scene file, samples, depth, seed and jitter through the software backend: the same image,
     bit for bit, as the CPU oracle (and so as the HIP backend's exact build), ray count included."""

@@ -9,6 +9,7 @@
 import ctypes
 
 import numpy as np
+import pytest
 
 import oracle
 
@@ -23,23 +24,54 @@ def test_keys_are_a_pure_function_of_seed_pixel_sample():
     assert L.orc_path_key(8, 3, 4) != L.orc_path_key(7, 3, 4)
 
 
-def test_subpixel_offsets_are_uniform():
+def sample_offsets(spp, pixel, seed=1):
+    import ctypes
+
     L = oracle.lib()
-    keys = np.array([L.orc_path_key(1, p, s) for p in range(64) for s in range(512)], dtype=np.uint64)
-    jx = (keys >> 16).astype(np.float64) / 65536.0
-    jy = (keys & 0xFFFF).astype(np.float64) / 65536.0
-    for j in (jx, jy):
+    term = L.orc_pixel_term(seed, pixel)
+    jx, jy = ctypes.c_float(), ctypes.c_float()
+    out = np.zeros((spp, 2))
+    for s in range(spp):
+        L.orc_sample_offset(spp, s, term, ctypes.byref(jx), ctypes.byref(jy))
+        out[s] = (jx.value, jy.value)
+    return out
+
+
+@pytest.mark.parametrize("spp", [1, 2, 3, 4, 5, 16, 64, 70, 256, 1000, 1024])
+def test_sample_positions_are_one_per_cell_of_a_grid_over_the_pixel(spp):
+    """The pixel's samples sit one per cell of a grid: rows of 2^floor(log2(spp)/2) cells, a shorter
+    last row at its own cell width, row heights in proportion to the rows' sample counts; every
+    sample at the pixel's own offset inside its cell."""
+    L = oracle.lib()
+    nx = 1 << L.orc_sample_row_length_log2(spp)
+    assert nx * nx <= spp < 4 * nx * nx
+    for pixel in (0, 7, 123456):
+        o = sample_offsets(spp, pixel)
+        assert np.all(o >= 0.0) and np.all(o < 1.0)
+        term = L.orc_pixel_term(1, pixel)
+        rx, ry = (term >> 16) / 65536.0, (term & 0xFFFF) / 65536.0
+        for s in range(spp):
+            r, i = divmod(s, nx)
+            n_r = min(nx, spp - r * nx)
+            assert abs(o[s, 0] - (i + rx) / n_r) < 1e-6
+            assert abs(o[s, 1] - (r * nx + ry * n_r) / spp) < 1e-6
+        # the cells tile the pixel: cell areas (1 / n_r) x (n_r / spp) are all 1 / spp
+
+
+def test_sample_positions_are_uniform_over_pixels():
+    """Over many pixels (their offsets are the halves of a hash) a given cell's sample is uniform
+    in the cell, so all samples together are uniform in the pixel."""
+    o = np.array([sample_offsets(1, p)[0] for p in range(8192)])      # one cell: the offset itself
+    for j in (o[:, 0], o[:, 1]):
         assert abs(j.mean() - 0.5) < 0.01
         assert abs(j.var() - 1.0 / 12.0) < 0.004
         hist, _ = np.histogram(j, bins=16, range=(0, 1))
         expected = len(j) / 16
         chi2 = float(((hist - expected) ** 2 / expected).sum())
         assert chi2 < 45.0                      # 15 degrees of freedom, p ~ 1e-4
-    assert abs(np.corrcoef(jx, jy)[0, 1]) < 0.02
-    # within one pixel the samples differ, and two pixels do not share offsets
-    k0 = keys[:512]
-    k1 = keys[512:1024]
-    assert len(set(k0.tolist())) == 512 and not np.array_equal(k0, k1)
+    # the offset inside the cell: x and y parts uncorrelated, pixels do not share offsets
+    assert abs(np.corrcoef(o[:, 0], o[:, 1])[0, 1]) < 0.05
+    assert len({tuple(v) for v in o.tolist()}) > 8000
 
 
 def test_generator_steps_like_pcg32():
