@@ -42,7 +42,7 @@ constexpr int kTileW = 16;               // path pass: a 256-thread workgroup co
 constexpr int kTileH = 16;               // each wave64 a 16x4 strip (coherent rays, 64-B row segments)
 constexpr int kBlock = kTileW * kTileH;
 constexpr int kLdsSpheres = 2048;        // shape-list chunk staged in LDS: 2048 x 16 B = 32 KiB
-constexpr int kPrimaryBlock = 256;       // primary pass: 256 threads x 4 pixels each
+constexpr int kPrimaryBlock = 512;       // primary pass: 512 threads x 4 pixels each
 constexpr float kTMin = 0.001f;
 constexpr int kTraceParts = 5;           // aehip_backend_trace renders a large band in this many parts so that
                                          // the copy of one part to the host overlaps the render of the next;
@@ -329,8 +329,16 @@ __device__ __forceinline__ f3 primary_pixel_reference(const f3 cam, const f3 oc,
     const float b = -2.0f * dot3<true>(d, oc);
     const float disc = b * b - (4.0f * a) * c;
     if(!(disc >= 0.0f)) return bg;
-    // src/shapes.cpp:23-25 : nearest root, no range test
-    const float t = (-b - rt_sqrt<true>(disc)) / (2.0f * a);
+    // src/shapes.cpp:23-25 : nearest root, no range test.  Square root and division through the
+    // short sequences of rt_exact_math.h where the operands allow (same bits), else the compiler's.
+    const float a2 = 2.0f * a;
+    float t;
+    if(disc >= rt_exact::kSqrtTameLo && disc <= rt_exact::kTameHi) {
+        const float num = -b - rt_exact::sqrt_tame(disc);
+        t = (rt_exact::tame(num) && rt_exact::tame(a2)) ? rt_exact::div_tame(num, a2) : num / a2;
+    } else {
+        t = (-b - rt_sqrt<true>(disc)) / a2;
+    }
     const f3 p = {d.x * t + cam.x, d.y * t + cam.y, d.z * t + cam.z};
     const f3 n = normalize3<true>(f3{p.x - ctr.x, p.y - ctr.y, p.z - ctr.z});
     return f3{remap_unit(n.x), remap_unit(n.y), remap_unit(n.z)};
