@@ -103,3 +103,24 @@ def test_frame_band_arithmetic_equals_the_python_sharding(n, rows, tile):
         expect_before += count.value
         seen += band_image_rows(dict(row_begin=first.value, row_count=count.value, tile_rows=tile if n > 1 else 0, tile_stride=tile * n))
     assert sorted(seen) == list(range(rows))
+
+
+def test_committed_counters_were_measured_on_these_kernel_sources():
+    """bench.py prices its roofline figures from profiles/r02_counters.json and refuses a file
+    collected on another version of the kernels: keep the committed file current (re-run
+    tools/profile_bench.sh and tools/profile_scenes.sh on the GPU box after changing a kernel)."""
+    import hashlib
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r02_counters.json")) as f:
+        doc = json.load(f)
+    h = hashlib.sha256()
+    for rel in doc["kernel_sources"]:
+        with open(os.path.join(root, rel), "rb") as f:
+            h.update(f.read())
+    assert doc["kernel_source_sha256"] == h.hexdigest()
+    for key in ("headline_fast", "headline_exact", "stress10k_1080p_4spp_d4_fast", "stress10k_1080p_4spp_d4_exact",
+                "stress10k_1080p_2spp_d1_fast", "divergence_1080p_16spp_d50_fast", "divergence_1080p_16spp_d50_exact"):
+        kernels = doc["workloads"][key]["kernels"]
+        assert any("executed_fp32_flop_per_frame" in k for k in kernels.values()), key

@@ -20,4 +20,7 @@ timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o pmc -- $BE
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" -o pmc -- $BENCH > "$OUT/pmc_write.log" 2>&1 || exit 4
 cd "$ROOT" && mkdir -p gpurun_out/profiles_out && python3 tools/collect_counters.py headline_$MODE $((STEPS + WARMUP + 1)) "$OUT" || exit 6
 cp profiles/r02_counters.json gpurun_out/profiles_out/r02_counters.json
+python3 tools/summarize_profile.py "$OUT" "$OUT/summary.txt" > /dev/null || exit 7
+# the rocpd databases are tens of MiB a run: keep the summaries, drop the databases unless asked
+[ -n "$KEEP_DB" ] || rm -rf "$OUT"/trace "$OUT"/pmc_*
 echo profile_ok

@@ -10,5 +10,6 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- python3 "$ROOT/tools/bench_primary.py" > "$OUT/trace.log" 2>&1 || exit 1
 timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d "$OUT/pmc_sq" -o pmc -- python3 "$ROOT/tools/bench_primary.py" --only-4k > "$OUT/pmc_sq.log" 2>&1 || exit 2
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" -o pmc -- python3 "$ROOT/tools/bench_primary.py" --only-4k > "$OUT/pmc_write.log" 2>&1 || exit 3
-cd "$ROOT" && python3 tools/summarize_profile.py "$OUT" "$OUT/summary.txt" > /dev/null
+cd "$ROOT" && python3 tools/summarize_profile.py "$OUT" "$OUT/summary.txt" > /dev/null || exit 4
+[ -n "$KEEP_DB" ] || rm -rf "$OUT"/trace "$OUT"/pmc_*
 echo profile_ok

@@ -19,7 +19,10 @@ for CASE in stress10k_1080p_2spp_d1 stress10k_1080p_4spp_d4 divergence_1080p_16s
         > "$OUT/$CASE/pmc_sq.log" 2>&1 || exit 2
     timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT GRBM_GUI_ACTIVE -d "$OUT/$CASE/pmc_flops" -o pmc -- python3 "$ROOT/tools/bench_scenes.py" --mode "$MODE" --reps $REPS --case $CASE \
         > "$OUT/$CASE/pmc_flops.log" 2>&1 || exit 3
-    (cd "$ROOT" && python3 tools/collect_counters.py ${CASE}_$MODE $REPS "$OUT/$CASE") || exit 4
+    (cd "$ROOT" && python3 tools/collect_counters.py ${CASE}_$MODE $REPS "$OUT/$CASE" && python3 tools/summarize_profile.py "$OUT/$CASE" "$OUT/$CASE.txt" > /dev/null) || exit 4
+    [ -n "$KEEP_DB" ] || rm -rf "$OUT/$CASE"
 done
+(cd "$ROOT" && python3 tools/summarize_profile.py "$OUT" "$OUT/trace.txt" > /dev/null) || exit 5
+[ -n "$KEEP_DB" ] || rm -rf "$OUT/trace"
 mkdir -p "$ROOT/gpurun_out/profiles_out" && cp "$ROOT/profiles/r02_counters.json" "$ROOT/gpurun_out/profiles_out/r02_counters.json"
 echo profile_ok
