@@ -130,6 +130,54 @@ PROBE_KERNEL(k_max3, X4(ROT16(I_MAX3)))
 PROBE_KERNEL(k_mov_sgpr, X4(ROT16(I_MOV_S)))
 PROBE_KERNEL(k_camera_sample, ROT16(I_SAMPLE))      // 16 samples x 8 instructions = 128 per iteration
 
+// FP32 MFMA beside the vector unit: v_mfma_f32_32x32x2_f32 on four independent accumulator tiles
+// (a[0:63]), alone and with FILL v_fma_f32 issued after each -- does the vector unit keep its rate
+// while the matrix pipe runs?  One "instruction" of the report is one MFMA (4,096 flop a wave) plus
+// its fillers.
+#define MFMA4 "v_mfma_f32_32x32x2_f32 a[0:15], v32, v33, a[0:15]\n" FILL "v_mfma_f32_32x32x2_f32 a[16:31], v34, v35, a[16:31]\n" FILL \
+              "v_mfma_f32_32x32x2_f32 a[32:47], v36, v37, a[32:47]\n" FILL "v_mfma_f32_32x32x2_f32 a[48:63], v38, v39, a[48:63]\n" FILL
+#define MFMA_KERNEL(NAME)                                                                                              \
+    __global__ __launch_bounds__(256) void NAME(stamp *out, int iters, float operand) {                              \
+        unsigned long long t0, t1, r0, r1;                                                                             \
+        asm volatile("v_mov_b32 v16, 1.0\n v_mov_b32 v17, 1.0\n v_mov_b32 v18, 1.0\n v_mov_b32 v19, 1.0\n"           \
+                     "v_mov_b32 v20, 1.0\n v_mov_b32 v21, 1.0\n v_mov_b32 v22, 1.0\n v_mov_b32 v23, 1.0\n"           \
+                     "v_mov_b32 v32, 0x3a83126f\n v_mov_b32 v33, 0x3a83126f\n v_mov_b32 v34, 0x3a83126f\n v_mov_b32 v35, 0x3a83126f\n" \
+                     "v_mov_b32 v36, 0x3a83126f\n v_mov_b32 v37, 0x3a83126f\n v_mov_b32 v38, 0x3a83126f\n v_mov_b32 v39, 0x3a83126f\n" \
+                     "v_mov_b32 v48, 0x38d1b717\n v_mov_b32 v49, 0x3f7ff972\n"                                         \
+                     ::: "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v48", "v49"); \
+        t0 = __builtin_amdgcn_s_memtime();                                                                             \
+        r0 = __builtin_amdgcn_s_memrealtime();                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(t0), "s"(r0));                                                      \
+        asm volatile("s_mov_b32 s20, %0\n"                                                                             \
+                     "1:\n" MFMA4 MFMA4 MFMA4 MFMA4 "s_sub_u32 s20, s20, 1\n s_cmp_lg_u32 s20, 0\n s_cbranch_scc1 1b\n"   \
+                     :: "s"(iters), "s"(operand)                                                                       \
+                     : "s20", "scc", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8",  \
+                       "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25",      \
+                       "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42",     \
+                       "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59",     \
+                       "a60", "a61", "a62", "a63");                                                                    \
+        t1 = __builtin_amdgcn_s_memtime();                                                                             \
+        r1 = __builtin_amdgcn_s_memrealtime();                                                                         \
+        if((threadIdx.x & 63u) == 0u) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = stamp{t1 - t0, r1 - r0};     \
+    }
+#define F8 "v_fma_f32 v16, v16, v49, v48\n v_fma_f32 v17, v17, v49, v48\n v_fma_f32 v18, v18, v49, v48\n v_fma_f32 v19, v19, v49, v48\n" \
+           "v_fma_f32 v20, v20, v49, v48\n v_fma_f32 v21, v21, v49, v48\n v_fma_f32 v22, v22, v49, v48\n v_fma_f32 v23, v23, v49, v48\n"
+#define FILL ""
+MFMA_KERNEL(k_mfma_f32)
+#undef FILL
+#define FILL F8
+MFMA_KERNEL(k_mfma_f32_8fma)
+#undef FILL
+#define FILL F8 F8
+MFMA_KERNEL(k_mfma_f32_16fma)
+#undef FILL
+#define FILL F8 F8 F8
+MFMA_KERNEL(k_mfma_f32_24fma)
+#undef FILL
+#define FILL F8 F8 F8 F8
+MFMA_KERNEL(k_mfma_f32_32fma)
+#undef FILL
+
 typedef void (*probe_fn)(stamp *, int, float);
 
 void run(const char *name, probe_fn fn, int per_iteration, double flop_per_lane_op, int cus, double realtime_hz, stamp *d_out) {
@@ -198,6 +246,12 @@ int main() {
     run("max3", k_max3, 64, 0, cus, hz, d_out);
     run("mov_from_sgpr", k_mov_sgpr, 64, 0, cus, hz, d_out);
     run("camera_sample_mix", k_camera_sample, 128, 1, cus, hz, d_out);
+    // one unit = one v_mfma_f32_32x32x2_f32 (64 flop a lane) and the v_fma_f32 issued after it (2 flop a lane each)
+    run("mfma_f32_32x32x2", k_mfma_f32, 16, 64, cus, hz, d_out);
+    run("mfma+8fma", k_mfma_f32_8fma, 16, 64 + 16, cus, hz, d_out);
+    run("mfma+16fma", k_mfma_f32_16fma, 16, 64 + 32, cus, hz, d_out);
+    run("mfma+24fma", k_mfma_f32_24fma, 16, 64 + 48, cus, hz, d_out);
+    run("mfma+32fma", k_mfma_f32_32fma, 16, 64 + 64, cus, hz, d_out);
     HIPCHK(hipFree(d_out));
     return 0;
 }
