@@ -254,6 +254,41 @@ def test_fast_path_pass_converges_to_the_oracle_image():
     assert psnr(fast_rgba[..., :3], exact_rgba[..., :3]) >= 40.0
 
 
+def test_headline_frame_fast_build_within_1e5_of_the_exact_build():
+    """The benchmark's own frame (3840x2160, 1024 samples on the grid): the fast build's averaged
+    colour is within 1e-5 of the bit-exact build's on every pixel (measured 2.1e-6, 127 dB)."""
+    w, h = 3840, 2160
+    _, fast_rgba, _ = render_device(w, h, spp=1024, max_depth=8, seed=1, jitter=True, fast=True)
+    _, exact_rgba, _ = render_device(w, h, spp=1024, max_depth=8, seed=1, jitter=True)
+    assert float(np.abs(fast_rgba - exact_rgba).max()) <= 1e-5
+
+
+def test_benchmark_size_path_traced_images_against_the_cpu_image_and_the_exact_build():
+    """Converged-image bounds at benchmark size (1920x1080).  Materials scene, 256 samples, depth 8:
+    the GPU image against the CPU oracle's with ANOTHER seed -- two estimates of the same image --
+    >= 38 dB for either build (measured 41.8), and the exact build with the oracle's seed is the
+    oracle's image bit for bit; fast against exact with the same seed >= 70 dB (85).  Depth-50 mixed
+    materials at 16 samples and 10,000 spheres at 4 samples, depth 4: fast against exact with the
+    same seed >= 45 dB (52) and >= 22 dB (26.8; paths part ways where a rounding flips a branch, and
+    at 4 samples one parted path is a quarter of the pixel) -- each far above what two seeds of
+    the exact build give against each other (28.7 and 17.0 dB)."""
+    w, h = 1920, 1080
+    sph = scenes.showcase_scene()
+    _, ref, _, _ = oracle.trace_paths(w, h, spp=256, max_depth=8, seed=101, jitter=True, spheres=sph, threads=16, want_rgba=True)
+    _, fast, _ = render_device(w, h, spp=256, max_depth=8, seed=202, jitter=True, spheres=sph, fast=True)
+    _, exact, _ = render_device(w, h, spp=256, max_depth=8, seed=202, jitter=True, spheres=sph)
+    _, same, _ = render_device(w, h, spp=256, max_depth=8, seed=101, jitter=True, spheres=sph)
+    np.testing.assert_array_equal(same.view(np.uint32), ref.view(np.uint32))
+    assert psnr(fast[..., :3], ref[..., :3]) >= 38.0
+    assert psnr(exact[..., :3], ref[..., :3]) >= 38.0
+    assert psnr(fast[..., :3], exact[..., :3]) >= 70.0
+    for sph, kw, bound in ((scenes.divergence_scene(300, 7), dict(spp=16, max_depth=50, seed=7), 45.0),
+                           (scenes.stress_scene(10000, 42), dict(spp=4, max_depth=4, seed=1), 22.0)):
+        _, fast, _ = render_device(w, h, jitter=True, spheres=sph, fast=True, **kw)
+        _, exact, _ = render_device(w, h, jitter=True, spheres=sph, **kw)
+        assert psnr(fast[..., :3], exact[..., :3]) >= bound
+
+
 def test_fast_default_scene_jittered_matches_exact_closely():
     _, fast_rgba, _ = render_device(256, 144, spp=64, max_depth=1, seed=1, jitter=True, fast=True)
     _, exact_rgba, _ = render_device(256, 144, spp=64, max_depth=1, seed=1, jitter=True)
