@@ -39,8 +39,8 @@ class CheckedGather(BandGather):
         super().__init__(*a, **kw)
         self.seen = []
 
-    def _assemble(self):
-        out = super()._assemble()
+    def _assemble(self, slot=0):
+        out = super()._assemble(slot)
         self.seen.append(self.image[::37, ::41].clone())
         return out
 
