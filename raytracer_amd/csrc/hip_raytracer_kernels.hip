@@ -1363,7 +1363,14 @@ __global__ __launch_bounds__(kBlock) void resolve_block_kernel(view_consts vc, c
 // launch renders the listed pixels with the exact build's code and leaves them out of its own.
 // ------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ bool pixel_needs_reference(const view_consts &vc, const camera_consts &cc, uint32_t x, uint32_t y) {
+// What the bounds over a pixel's sample positions say about its samples (single-sphere camera pass).
+struct pixel_class {
+    bool may_hit;               // false: every sample misses, by more than the screening margin
+    bool well_conditioned;      // every sample hits, with conditioning value q >= kExactBelowQ
+    bool faces_sphere;          // h = draw.oc > 0 at the pixel (h keeps its sign over a pixel whose samples all hit)
+};
+
+__device__ __forceinline__ pixel_class classify_pixel(const view_consts &vc, const camera_consts &cc, uint32_t x, uint32_t y) {
     const bool jitter = (vc.flags & AEHIP_FLAG_JITTER) != 0;
     // the sample positions of the pixel span [u0, u0 + eu] x [v0, v0 + ev] on the viewport,
     // measured from the camera (a single point without jitter)
@@ -1372,7 +1379,7 @@ __device__ __forceinline__ bool pixel_needs_reference(const view_consts &vc, con
     const float v0 = __builtin_fmaf(yb, vc.psy, -(vc.vh_half + vc.cam[1]));
     const float eu = jitter ? vc.psx : 0.0f, ev = jitter ? vc.psy : 0.0f;
     const float dz = 0.0f - vc.cam[2];
-    float disc_min = 3.402823466e+38f, disc_max = -3.402823466e+38f, big_max = 0.0f;
+    float disc_min = 3.402823466e+38f, disc_max = -3.402823466e+38f, big_max = 0.0f, h_corner = 0.0f;
 #pragma unroll
     for(int k = 0; k < 4; k++) {
         const float u = u0 + ((k & 1) ? eu : 0.0f), v = v0 + ((k & 2) ? ev : 0.0f);
@@ -1382,6 +1389,7 @@ __device__ __forceinline__ bool pixel_needs_reference(const view_consts &vc, con
         disc_min = fminf(disc_min, disc);
         disc_max = fmaxf(disc_max, disc);
         big_max = fmaxf(big_max, __builtin_fmaf(dd, cc.magnitude, h * h));
+        if(k == 0) h_corner = h;
     }
     // smallest dd over the rectangle: each coordinate at its smallest magnitude
     const float ua = (u0 <= 0.0f && u0 + eu >= 0.0f) ? 0.0f : fminf(fabsf(u0), fabsf(u0 + eu));
@@ -1390,10 +1398,19 @@ __device__ __forceinline__ bool pixel_needs_reference(const view_consts &vc, con
     // the discriminant is a quadratic in (u, v): inside the rectangle it leaves the range of
     // the corner values by at most its second-order terms; plus the evaluations' own rounding
     const float pad = fabsf(cc.q_uu) * eu * eu + fabsf(cc.q_uv) * eu * ev + fabsf(cc.q_vv) * ev * ev + 1e-5f * big_max;
-    const bool may_hit = disc_max + pad >= -(kScreenMargin * 1.01f) * big_max;
+    pixel_class pc;
+    // (the magnitude h*h + dd*(oc.oc + r*r) is a sum of squares of linear forms: over the rectangle it
+    // is largest at a corner, so big_max bounds it for every sample)
+    pc.may_hit = disc_max + pad >= -(kScreenMargin * 1.01f) * big_max;
     // q >= kExactBelowQ for every sample of the pixel, with 5 % to spare; false for NaN / inf: such pixels are listed
-    const bool well_conditioned = (disc_min - pad) * (dd_min * cc.radius2) >= (kExactBelowQ * 1.05f) * (big_max * big_max);
-    return may_hit && !well_conditioned;
+    pc.well_conditioned = (disc_min - pad) * (dd_min * cc.radius2) >= (kExactBelowQ * 1.05f) * (big_max * big_max);
+    pc.faces_sphere = h_corner > 0.0f;
+    return pc;
+}
+
+__device__ __forceinline__ bool pixel_needs_reference(const view_consts &vc, const camera_consts &cc, uint32_t x, uint32_t y) {
+    const pixel_class pc = classify_pixel(vc, cc, x, y);
+    return pc.may_hit && !pc.well_conditioned;
 }
 
 __global__ __launch_bounds__(256) void ring_pixels_kernel(view_consts vc, camera_consts cc, uint32_t *__restrict__ count,
@@ -1448,7 +1465,7 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                                             const float4 *__restrict__ geom, const uint32_t *__restrict__ sample_terms,
                                             uint32_t *__restrict__ argb, float4 *__restrict__ rgba, uint32_t group_x,
                                             uint32_t group_y, const uint32_t *__restrict__ pixel_list, uint32_t list_count,
-                                            uint32_t list_row_bias) {
+                                            uint32_t list_row_bias, const float4 *__restrict__ row_miss) {
     constexpr uint32_t kWaves = kBlock / 64;
     __shared__ float4 s_occ[ONE ? 1 : kLdsSpheres];     // oc.xyz, c
     __shared__ float4 s_ctr[ONE ? 1 : kLdsSpheres];     // centre.xyz, oc.oc + r*r
@@ -1471,7 +1488,30 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
         row = (packed >> 16) - list_row_bias;      // entries hold rows of the whole band; a launch may render part of it
     }
     const uint32_t y = image_row(vc, row);
-    if constexpr(SKIP_LISTED) valid = valid && !pixel_needs_reference(vc, cc, x, y);
+    // One sphere: bounds over the pixel's sample positions (classify_pixel) say of all but the
+    // pixels along the silhouette that every sample misses or that every sample hits.
+    //  - every sample misses: the pixel stays out of the sample loop.  Its value is the row
+    //    background summed spp times -- in the fast build a product, in the exact build the sum in
+    //    sample order that set-up tabulated per image row (row_miss; without the table the exact
+    //    build culls nothing).
+    //  - every sample hits, well conditioned, near root (fast build): the hit loop, which neither
+    //    tests nor branches.
+    // Everything else goes through the general loop.
+    bool culled = false, sure_hit = false;
+    if constexpr(ONE) {
+        if(!pixel_list && (!EXACT || row_miss != nullptr)) {
+            const pixel_class pc = classify_pixel(vc, cc, x, y);
+            if constexpr(SKIP_LISTED) valid = valid && !(pc.may_hit && !pc.well_conditioned);
+            culled = !pc.may_hit;
+            if constexpr(!EXACT) {
+                if(cc.near_root_only != 0u && pc.may_hit && pc.well_conditioned) {
+                    sure_hit = pc.faces_sphere;
+                    culled = !pc.faces_sphere;         // the sphere is behind the camera: no root counts
+                }
+            }
+        }
+    }
+    const bool work = valid && !culled;
     const f3 cam = {vc.cam[0], vc.cam[1], vc.cam[2]};
     const uint32_t n_spheres = ONE ? 1u : vc.n_spheres;
     const uint32_t nblocks = (vc.spp + AEHIP_SAMPLE_BLOCK - 1u) / AEHIP_SAMPLE_BLOCK;
@@ -1548,11 +1588,43 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
 
     f3 sum = {0.0f, 0.0f, 0.0f};
 
+    auto write_pixel = [&]() {
+        if(valid && part == 0u) {
+            if constexpr(EXACT && ONE) {
+                if(culled) {
+                    const float4 t = row_miss[y];
+                    sum = f3{t.x, t.y, t.z};
+                }
+            }
+            const float n = static_cast<float>(vc.spp);
+            // the mean is a true division in both builds (once per pixel): an approximate reciprocal
+            // would turn a row of exact 1.0 samples into 0.99999994 and the truncating pack into 254
+            const float r = clamp01(sum.x / n);
+            const float g = clamp01(sum.y / n);
+            const float b = clamp01(sum.z / n);
+            const size_t idx = static_cast<size_t>(row) * vc.width + x;
+            argb[idx] = pack_argb32(r, g, b);
+            if(rgba) rgba[idx] = make_float4(r, g, b, 1.0f);
+        }
+    };
+
+    if constexpr(ONE) {
+        // a workgroup none of whose pixels is in the sample loop (most of the frame around the sphere)
+        if(__syncthreads_or(work ? 1 : 0) == 0) {
+            if constexpr(!EXACT) {
+                const float misses = static_cast<float>(vc.spp);
+                sum = f3{misses * bg.x, misses * bg.y, misses * bg.z};
+            }
+            write_pixel();
+            return;
+        }
+    }
+
     if constexpr(EXACT) {
         for(uint32_t first = 0; first < nblocks; first += split) {      // a round: `split` consecutive blocks
             const uint32_t blk = first + part;
             f3 block = {0.0f, 0.0f, 0.0f};
-            if(blk < nblocks && valid) {
+            if(blk < nblocks && work) {
                 const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
                 const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
                 for(uint32_t s = s0; s < s1;) {
@@ -1699,10 +1771,43 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
         // along `draw`); only hits add to the sum, misses are counted and added as
         // (misses * background); the order of additions is free
         uint32_t hits = 0;
+        f3 hit = {0.0f, 0.0f, 0.0f};        // the hit loop's sums, before the factor shade_scale
         for(uint32_t blk = part; blk < nblocks; blk += split) {
             const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
             const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
-            if(!valid) continue;
+            if constexpr(ONE) {
+                if(sure_hit) {
+                    // The hit loop: every sample of the pixel hits at the near root (see the
+                    // general loop below for the algebra).  Eleven vector instructions a sample,
+                    // no test and no branch; the factor shade_scale is applied to the sums.
+                    for(uint32_t s = s0; s < s1;) {
+                        const cell_row cr = row_at(s, s1);
+                        s += cr.count;
+                        const float v = __builtin_fmaf(cr.jy, vc.psy, uy0);
+                        const float du = jitter ? vc.psx * cr.inv_cells : 0.0f;
+                        float u = __builtin_fmaf(jitter ? (cr.first + off.rx) * cr.inv_cells : 0.5f, vc.psx, ux0) - du;
+                        const float qb = __builtin_fmaf(cc.q_uv, v, cc.q_u);
+                        const float qc = __builtin_fmaf(v, __builtin_fmaf(cc.q_vv, v, cc.q_v), cc.q_0);
+                        const float h_row = __builtin_fmaf(v, cc.oc[1], dz * cc.oc[2]);
+                        const float dd_row = __builtin_fmaf(v, v, dz2);
+                        float row_scale = 0.0f;
+#pragma unroll 4
+                        for(uint32_t k = 0; k < cr.count; k++) {
+                            u += du;
+                            const float disc = __builtin_fmaf(u, __builtin_fmaf(cc.q_uu, u, qb), qc);
+                            const float dd = __builtin_fmaf(u, u, dd_row);
+                            const float h = __builtin_fmaf(u, cc.oc[0], h_row);
+                            const float sc = (h - __builtin_amdgcn_sqrtf(disc)) * __builtin_amdgcn_rcpf(dd);
+                            hit.x = __builtin_fmaf(u, sc, hit.x);
+                            row_scale += sc;
+                        }
+                        hit.y = __builtin_fmaf(v, row_scale, hit.y);
+                        hit.z += row_scale;
+                        hits += cr.count;
+                    }
+                }
+            }
+            if(!work || sure_hit) continue;
             for(uint32_t s = s0; s < s1;) {
                 const cell_row cr = row_at(s, s1);
                 s += cr.count;
@@ -1795,6 +1900,11 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                 }
             }
         }
+        if constexpr(ONE) {
+            sum.x = __builtin_fmaf(hit.x, cc.shade_scale, sum.x);
+            sum.y = __builtin_fmaf(hit.y, cc.shade_scale, sum.y);
+            sum.z = __builtin_fmaf(hit.z, cc.shade_scale, sum.z);
+        }
         if(split > 1u) {
             s_part[0][wave][0][lane] = sum.x;
             s_part[0][wave][1][lane] = sum.y;
@@ -1823,17 +1933,7 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
         sum.z = __builtin_fmaf(misses, bg.z, sum.z);
     }
 
-    if(valid && part == 0u) {
-        const float n = static_cast<float>(vc.spp);
-        // the mean is a true division in both builds (once per pixel): an approximate reciprocal
-        // would turn a row of exact 1.0 samples into 0.99999994 and the truncating pack into 254
-        const float r = clamp01(sum.x / n);
-        const float g = clamp01(sum.y / n);
-        const float b = clamp01(sum.z / n);
-        const size_t idx = static_cast<size_t>(row) * vc.width + x;
-        argb[idx] = pack_argb32(r, g, b);
-        if(rgba) rgba[idx] = make_float4(r, g, b, 1.0f);
-    }
+    write_pixel();
 
     // (Ray and lane-slot counts of this pass follow from the image size -- one ray per sample,
     // every lane of a strip busy for each of its samples -- and are filled in by the host.)
@@ -1843,8 +1943,33 @@ template <bool EXACT, bool ONE, bool FOLD, bool AXIAL>
 __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_consts cc, uint32_t split_log2,
                                                         const float4 *__restrict__ geom,
                                                         const uint32_t *__restrict__ sample_terms,
-                                                        uint32_t *__restrict__ argb, float4 *__restrict__ rgba) {
-    camera_body<EXACT, ONE, FOLD, AXIAL, false>(vc, cc, split_log2, geom, sample_terms, argb, rgba, blockIdx.x, blockIdx.y, nullptr, 0u, 0u);
+                                                        uint32_t *__restrict__ argb, float4 *__restrict__ rgba,
+                                                        const float4 *__restrict__ row_miss) {
+    camera_body<EXACT, ONE, FOLD, AXIAL, false>(vc, cc, split_log2, geom, sample_terms, argb, rgba, blockIdx.x, blockIdx.y, nullptr, 0u, 0u,
+                                                row_miss);
+}
+
+// The exact build's value of a pixel whose samples all miss, before the division by spp: the row's
+// background added spp times in the camera pass's order (blocks of AEHIP_SAMPLE_BLOCK samples, then
+// the block sums).  One entry per image row; one thread per row.
+__global__ __launch_bounds__(64) void row_miss_sums_kernel(view_consts vc, uint32_t image_rows, float4 *__restrict__ out) {
+    const uint32_t y = blockIdx.x * 64u + threadIdx.x;
+    if(y >= image_rows) return;
+    const f3 bg = row_background<true>(vc, y);
+    f3 sum = {0.0f, 0.0f, 0.0f};
+    for(uint32_t s0 = 0; s0 < vc.spp; s0 += AEHIP_SAMPLE_BLOCK) {
+        const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
+        f3 block = {0.0f, 0.0f, 0.0f};
+        for(uint32_t s = s0; s < s1; s++) {
+            block.x += bg.x;
+            block.y += bg.y;
+            block.z += bg.z;
+        }
+        sum.x += block.x;
+        sum.y += block.y;
+        sum.z += block.z;
+    }
+    out[y] = make_float4(sum.x, sum.y, sum.z, 0.0f);
 }
 
 // The fast build's single-sphere launch when the band has ill-conditioned pixels: the first
@@ -1863,11 +1988,12 @@ __global__ __launch_bounds__(kBlock, 8) void camera_hybrid_kernel(view_consts vc
                                                                uint32_t list_row_bias, uint32_t list_groups, uint32_t groups_x) {
     if(blockIdx.x < list_groups) {
         camera_body<true, true, FOLD, AXIAL, false, true>(vc, cc, split_log2, nullptr, sample_terms, argb, rgba, blockIdx.x, 0u, pixel_list,
-                                                          list_count, list_row_bias);
+                                                          list_count, list_row_bias, nullptr);
     } else {
         const uint32_t id = blockIdx.x - list_groups;
         const uint32_t gy = id / groups_x;
-        camera_body<false, true, false, AXIAL, true>(vc, cc, split_log2, nullptr, sample_terms, argb, rgba, id - gy * groups_x, gy, nullptr, 0u, 0u);
+        camera_body<false, true, false, AXIAL, true>(vc, cc, split_log2, nullptr, sample_terms, argb, rgba, id - gy * groups_x, gy, nullptr, 0u, 0u,
+                                                     nullptr);
     }
 }
 
@@ -1961,6 +2087,8 @@ struct aehip_backend {
     size_t staging_capacity = 0;
     unsigned long long *d_rays = nullptr;    // ray segments, lane slots, unit queue of the streamed pass
     uint32_t *d_sample_terms = nullptr;      // spp + 1 words: per-sample key terms (+1 spare for prefetch)
+    float4 *d_row_miss = nullptr;            // per image row: an all-miss pixel's sum, exact build (row_miss_sums_kernel)
+    uint32_t row_miss_capacity = 0;
     uint32_t sample_terms_capacity = 0;
     uint32_t *d_ring = nullptr;              // fast single-sphere camera pass: pixels the exact kernel redoes, sorted by band row
     uint32_t ring_capacity = 0, ring_count = 0;
@@ -2093,7 +2221,7 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
     do {                                                                                                               \
         func = reinterpret_cast<const void *>(camera_kernel<E, O, F, A>);                                              \
         hipLaunchKernelGGL((camera_kernel<E, O, F, A>), grid, dim3(kBlock), 0, stream, vc, b->cc, split_log2,          \
-                           b->d_geom, b->d_sample_terms, argb_dev, rgba);                                              \
+                           b->d_geom, b->d_sample_terms, argb_dev, rgba, (E) && (O) && (F) ? b->d_row_miss : nullptr); \
     } while(0)
         // one ray per sample; a strip's 64 lanes run for each of its samples
         b->counts_known = true;
@@ -2299,6 +2427,7 @@ void aehip_backend_destroy(aehip_backend *b) {
     if(b->d_argb) (void)hipFree(b->d_argb);
     if(b->d_rays) (void)hipFree(b->d_rays);
     if(b->d_sample_terms) (void)hipFree(b->d_sample_terms);
+    if(b->d_row_miss) (void)hipFree(b->d_row_miss);
     if(b->d_radiance) (void)hipFree(b->d_radiance);
     if(b->ev_scratch) (void)hipEventDestroy(b->ev_scratch);
     if(b->h_staging) (void)hipHostFree(b->h_staging);
@@ -2541,6 +2670,18 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
     if((p.flags & AEHIP_FLAG_FAST) && p.pass == AEHIP_PASS_PATH && single_sphere_camera_pass(b)) {
         const int rc = build_ring_list(b);
         if(rc != AEHIP_OK) return rc;
+    }
+
+    // exact build, single-sphere camera pass: the value of the pixels whose samples all miss
+    if(!(p.flags & AEHIP_FLAG_FAST) && p.pass == AEHIP_PASS_PATH && single_sphere_camera_pass(b)) {
+        if(p.height > b->row_miss_capacity) {
+            if(b->d_row_miss) (void)hipFree(b->d_row_miss);
+            b->d_row_miss = nullptr; b->row_miss_capacity = 0;
+            AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_row_miss), sizeof(float4) * p.height));
+            b->row_miss_capacity = p.height;
+        }
+        hipLaunchKernelGGL(row_miss_sums_kernel, dim3((p.height + 63u) / 64u), dim3(64), 0, b->stream, vc, p.height, b->d_row_miss);
+        AEHIP_CHECK(hipGetLastError());
     }
 
     // per-sample key terms
