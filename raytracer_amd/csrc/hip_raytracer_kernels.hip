@@ -1581,7 +1581,10 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
         const uint32_t r = s >> vc.row_bits, n_r = cells_in_row(vc, r);
         cr.count = min(s_end, (r << vc.row_bits) + n_r) - s;
         cr.first = static_cast<float>(s & (row_cells - 1u));
-        cr.inv_cells = 1.0f / static_cast<float>(n_r);
+        // (a power of two in all rows but a ragged last one: its reciprocal comes from the exponent,
+        // in the scalar unit, instead of a division)
+        cr.inv_cells = (n_r & (n_r - 1u)) == 0u ? __uint_as_float((127u - static_cast<uint32_t>(__builtin_ctz(n_r))) << 23)
+                                                : 1.0f / static_cast<float>(n_r);
         cr.jy = (static_cast<float>(r << vc.row_bits) + off.ry * static_cast<float>(n_r)) * vc.inv_spp;
         return cr;
     };
@@ -1771,15 +1774,22 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
         // along `draw`); only hits add to the sum, misses are counted and added as
         // (misses * background); the order of additions is free
         uint32_t hits = 0;
-        f3 hit = {0.0f, 0.0f, 0.0f};        // the hit loop's sums, before the factor shade_scale
+        f3 hit = {0.0f, 0.0f, 0.0f};        // the hit loop's sums, before the factor c * shade_scale
+        // the hit loop's two per-sample constants, in vector registers: an instruction with a
+        // scalar-register operand issues at half the rate of one without (measured, tools/valu_peak.hip)
+        float q_uu_v = 0.0f, oc_x_v = 0.0f;
+        if constexpr(ONE) {
+            asm volatile("v_mov_b32 %0, %1" : "=v"(q_uu_v) : "s"(cc.q_uu));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(oc_x_v) : "s"(cc.oc[0]));
+        }
         for(uint32_t blk = part; blk < nblocks; blk += split) {
             const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
             const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
             if constexpr(ONE) {
                 if(sure_hit) {
                     // The hit loop: every sample of the pixel hits at the near root (see the
-                    // general loop below for the algebra).  Eleven vector instructions a sample,
-                    // no test and no branch; the factor shade_scale is applied to the sums.
+                    // general loop below for the algebra).  Nine vector instructions a sample,
+                    // no test and no branch; the factor c * shade_scale is applied to the sums.
                     for(uint32_t s = s0; s < s1;) {
                         const cell_row cr = row_at(s, s1);
                         s += cr.count;
@@ -1789,15 +1799,15 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                         const float qb = __builtin_fmaf(cc.q_uv, v, cc.q_u);
                         const float qc = __builtin_fmaf(v, __builtin_fmaf(cc.q_vv, v, cc.q_v), cc.q_0);
                         const float h_row = __builtin_fmaf(v, cc.oc[1], dz * cc.oc[2]);
-                        const float dd_row = __builtin_fmaf(v, v, dz2);
                         float row_scale = 0.0f;
 #pragma unroll 4
                         for(uint32_t k = 0; k < cr.count; k++) {
                             u += du;
-                            const float disc = __builtin_fmaf(u, __builtin_fmaf(cc.q_uu, u, qb), qc);
-                            const float dd = __builtin_fmaf(u, u, dd_row);
-                            const float h = __builtin_fmaf(u, cc.oc[0], h_row);
-                            const float sc = (h - __builtin_amdgcn_sqrtf(disc)) * __builtin_amdgcn_rcpf(dd);
+                            const float disc = __builtin_fmaf(u, __builtin_fmaf(q_uu_v, u, qb), qc);
+                            const float h = __builtin_fmaf(u, oc_x_v, h_row);
+                            // the near root over dd, (h - sqrt(disc)) / dd, is c / (h + sqrt(disc)):
+                            // (h - s)(h + s) = h*h - disc = dd * c.  No cancellation, and dd is not needed.
+                            const float sc = __builtin_amdgcn_rcpf(h + __builtin_amdgcn_sqrtf(disc));
                             hit.x = __builtin_fmaf(u, sc, hit.x);
                             row_scale += sc;
                         }
@@ -1901,9 +1911,10 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
             }
         }
         if constexpr(ONE) {
-            sum.x = __builtin_fmaf(hit.x, cc.shade_scale, sum.x);
-            sum.y = __builtin_fmaf(hit.y, cc.shade_scale, sum.y);
-            sum.z = __builtin_fmaf(hit.z, cc.shade_scale, sum.z);
+            const float scale = cc.c * cc.shade_scale;
+            sum.x = __builtin_fmaf(hit.x, scale, sum.x);
+            sum.y = __builtin_fmaf(hit.y, scale, sum.y);
+            sum.z = __builtin_fmaf(hit.z, scale, sum.z);
         }
         if(split > 1u) {
             s_part[0][wave][0][lane] = sum.x;
