@@ -1497,18 +1497,36 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
     //  - every sample hits, well conditioned, near root (fast build): the hit loop, which neither
     //    tests nor branches.
     // Everything else goes through the general loop.
+    // The waves that share a strip share its pixels: the strip's first wave classifies, the
+    // others read the result (a class costs about a hundred vector instructions).
     bool culled = false, sure_hit = false;
+    bool group_idle = false;            // no pixel of the workgroup is in the sample loop
     if constexpr(ONE) {
         if(!pixel_list && (!EXACT || row_miss != nullptr)) {
-            const pixel_class pc = classify_pixel(vc, cc, x, y);
-            if constexpr(SKIP_LISTED) valid = valid && !(pc.may_hit && !pc.well_conditioned);
-            culled = !pc.may_hit;
-            if constexpr(!EXACT) {
-                if(cc.near_root_only != 0u && pc.may_hit && pc.well_conditioned) {
-                    sure_hit = pc.faces_sphere;
-                    culled = !pc.faces_sphere;         // the sphere is behind the camera: no root counts
+            constexpr uint32_t kCulled = 1u, kSureHit = 2u, kListed = 4u;
+            __shared__ uint32_t s_class[kWaves][64];
+            __shared__ uint32_t s_strip_work[kWaves];
+            uint32_t cls = 0;
+            if(part == 0u) {
+                const pixel_class pc = classify_pixel(vc, cc, x, y);
+                if(SKIP_LISTED && pc.may_hit && !pc.well_conditioned) cls |= kListed;
+                if(!pc.may_hit) cls |= kCulled;
+                if constexpr(!EXACT) {
+                    if(cc.near_root_only != 0u && pc.may_hit && pc.well_conditioned)
+                        cls |= pc.faces_sphere ? kSureHit : kCulled;       // behind the camera: no root counts
                 }
+                s_class[strip][lane] = cls;
+                const bool strip_work = __ballot(valid && (cls & (kCulled | kListed)) == 0u) != 0ull;
+                if(lane == 0u) s_strip_work[strip] = strip_work ? 1u : 0u;
             }
+            __syncthreads();
+            if(part != 0u) cls = s_class[strip][lane];
+            uint32_t any = 0;
+            for(uint32_t i = 0; i < (kWaves >> split_log2); i++) any |= s_strip_work[i];
+            group_idle = any == 0u;
+            valid = valid && (cls & kListed) == 0u;
+            culled = (cls & kCulled) != 0u;
+            sure_hit = (cls & kSureHit) != 0u;
         }
     }
     const bool work = valid && !culled;
@@ -1613,7 +1631,7 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
 
     if constexpr(ONE) {
         // a workgroup none of whose pixels is in the sample loop (most of the frame around the sphere)
-        if(__syncthreads_or(work ? 1 : 0) == 0) {
+        if(group_idle) {
             if constexpr(!EXACT) {
                 const float misses = static_cast<float>(vc.spp);
                 sum = f3{misses * bg.x, misses * bg.y, misses * bg.z};

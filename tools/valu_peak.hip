@@ -65,6 +65,34 @@
     "v_fma_f32 v0, v" #b ", v0, v3\n"                                                                                  \
     "v_cmp_le_f32 vcc, 0, v0\n"
 
+// one quarter-rate instruction among three full-rate ones: do they share the issue slots?
+#define I_RCP_FMA3(a, b, c)                                                                                            \
+    "v_rcp_f32 v" #a ", v" #a "\n"                                                                                     \
+    "v_fma_f32 v" #b ", v" #b ", v" #c ", v" #c "\n"                                                                   \
+    "v_fma_f32 v" #b ", v" #b ", v" #c ", v" #c "\n"                                                                   \
+    "v_fma_f32 v" #b ", v" #b ", v" #c ", v" #c "\n"
+// the fast camera pass's hitting sample: step, three fmas, square root, add, reciprocal, fma, add
+#define I_HIT(a, b, c)                                                                                                 \
+    "v_add_f32 v" #b ", v" #c ", v" #b "\n"                                                                            \
+    "v_fma_f32 v0, v1, v" #b ", v2\n"                                                                                  \
+    "v_fma_f32 v0, v" #b ", v0, v5\n"                                                                                  \
+    "v_fma_f32 v3, v" #b ", v4, v5\n"                                                                                  \
+    "v_sqrt_f32 v0, v0\n"                                                                                              \
+    "v_add_f32 v0, v3, v0\n"                                                                                           \
+    "v_rcp_f32 v0, v0\n"                                                                                               \
+    "v_fma_f32 v" #a ", v" #b ", v0, v" #a "\n"                                                                        \
+    "v_add_f32 v" #a ", v" #a ", v0\n"
+
+// the same nine instructions for four samples at a time, the quarter-rate ones back to back
+#define HIT_HEAD(u, d, h) "v_add_f32 v" #u ", v48, v" #u "\n v_fma_f32 v" #d ", v1, v" #u ", v2\n v_fma_f32 v" #d ", v" #u ", v" #d ", v5\n v_fma_f32 v" #h ", v" #u ", v4, v5\n"
+#define HIT_TAIL(u, d, a, b) "v_fma_f32 v" #a ", v" #u ", v" #d ", v" #a "\n v_add_f32 v" #b ", v" #b ", v" #d "\n"
+#define HIT_GROUPED                                                                                                    \
+    HIT_HEAD(32, 20, 24) HIT_HEAD(33, 21, 25) HIT_HEAD(34, 22, 26) HIT_HEAD(35, 23, 27)                                \
+    "v_sqrt_f32 v20, v20\n v_sqrt_f32 v21, v21\n v_sqrt_f32 v22, v22\n v_sqrt_f32 v23, v23\n"                        \
+    "v_add_f32 v20, v24, v20\n v_add_f32 v21, v25, v21\n v_add_f32 v22, v26, v22\n v_add_f32 v23, v27, v23\n"        \
+    "v_rcp_f32 v20, v20\n v_rcp_f32 v21, v21\n v_rcp_f32 v22, v22\n v_rcp_f32 v23, v23\n"                            \
+    HIT_TAIL(32, 20, 16, 28) HIT_TAIL(33, 21, 17, 29) HIT_TAIL(34, 22, 18, 30) HIT_TAIL(35, 23, 19, 31)
+
 // packed instructions use register pairs: 8 pair-accumulators
 #define PAIR8(OP) OP(16, 34, 52) OP(18, 36, 54) OP(20, 38, 56) OP(22, 40, 58) OP(24, 42, 60) OP(26, 44, 62) OP(28, 46, 48) OP(30, 32, 50)
 
@@ -129,6 +157,9 @@ PROBE_KERNEL(k_sqrt, X4(ROT16(I_SQRT)))
 PROBE_KERNEL(k_max3, X4(ROT16(I_MAX3)))
 PROBE_KERNEL(k_mov_sgpr, X4(ROT16(I_MOV_S)))
 PROBE_KERNEL(k_camera_sample, ROT16(I_SAMPLE))      // 16 samples x 8 instructions = 128 per iteration
+PROBE_KERNEL(k_rcp_fma3, X4(ROT16(I_RCP_FMA3)))     // 64 groups of 4 instructions
+PROBE_KERNEL(k_camera_hit, ROT16(I_HIT))            // 16 samples x 9 instructions = 144 per iteration
+PROBE_KERNEL(k_camera_hit_grouped, X4(HIT_GROUPED))
 
 // FP32 MFMA beside the vector unit: v_mfma_f32_32x32x2_f32 on four independent accumulator tiles
 // (a[0:63]), alone and with FILL v_fma_f32 issued after each -- does the vector unit keep its rate
@@ -246,6 +277,9 @@ int main() {
     run("max3", k_max3, 64, 0, cus, hz, d_out);
     run("mov_from_sgpr", k_mov_sgpr, 64, 0, cus, hz, d_out);
     run("camera_sample_mix", k_camera_sample, 128, 1, cus, hz, d_out);
+    run("rcp+3fma", k_rcp_fma3, 256, 7.0 / 4.0, cus, hz, d_out);
+    run("camera_hit_mix", k_camera_hit, 144, 13.0 / 9.0, cus, hz, d_out);
+    run("camera_hit_by_4", k_camera_hit_grouped, 144, 13.0 / 9.0, cus, hz, d_out);
     // one unit = one v_mfma_f32_32x32x2_f32 (64 flop a lane) and the v_fma_f32 issued after it (2 flop a lane each)
     run("mfma_f32_32x32x2", k_mfma_f32, 16, 64, cus, hz, d_out);
     run("mfma+8fma", k_mfma_f32_8fma, 16, 64 + 16, cus, hz, d_out);
