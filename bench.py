@@ -334,7 +334,8 @@ def main():
                 r["note"] = ("achieved = 64 x (ADD_F32 + MUL_F32 + 2 FMA_F32 + TRANS_F32) wave-instructions per launch (rocprofv3 "
                              "counters of this command, committed) / this run's launch time; algorithmic_tflops prices the flops of "
                              "the reference's formulas (36 per missing sample, 67 per hit) over the same time and may exceed the "
-                             "peak: the kernel decides misses with a 4-fma per-pixel quadratic and never normalises their rays")
+                             "peak: bounds over a pixel's sample positions decide the pixels whose samples all miss (78 % of this "
+                             "frame) without walking their samples, and the fast build's hits cost 9 instructions a sample")
             else:
                 r["note"] = counters_error or "executed-operation counters exist for the default workload (1024 spp, depth 8) only"
             return r

@@ -1964,8 +1964,9 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
 
     write_pixel();
 
-    // (Ray and lane-slot counts of this pass follow from the image size -- one ray per sample,
-    // every lane of a strip busy for each of its samples -- and are filled in by the host.)
+    // (Ray and lane-slot counts of this pass follow from the image size -- one ray per sample, a
+    // strip's 64 lanes counted for each of its samples, walked or decided by the pixel's bounds --
+    // and are filled in by the host.)
 }
 
 template <bool EXACT, bool ONE, bool FOLD, bool AXIAL>
@@ -2252,7 +2253,8 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         hipLaunchKernelGGL((camera_kernel<E, O, F, A>), grid, dim3(kBlock), 0, stream, vc, b->cc, split_log2,          \
                            b->d_geom, b->d_sample_terms, argb_dev, rgba, (E) && (O) && (F) ? b->d_row_miss : nullptr); \
     } while(0)
-        // one ray per sample; a strip's 64 lanes run for each of its samples
+        // one ray per sample, whether the sample loop walks it or the pixel's bounds decide it; a
+        // strip's 64 lanes are counted for each of its samples
         b->counts_known = true;
         b->known_rays = static_cast<uint64_t>(vc.width) * vc.row_count * vc.spp;
         b->known_lane_slots = static_cast<uint64_t>((vc.width + kTileW - 1) / kTileW) * ((vc.row_count + 3u) / 4u) * 64u * vc.spp;

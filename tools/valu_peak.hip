@@ -83,6 +83,42 @@
     "v_fma_f32 v" #a ", v" #b ", v0, v" #a "\n"                                                                        \
     "v_add_f32 v" #a ", v" #a ", v0\n"
 
+// the hitting sample with the reciprocal refined from the previous sample's (two fmas) instead of v_rcp_f32
+#define I_HIT_NEWTON(a, b, c)                                                                                          \
+    "v_add_f32 v" #b ", v" #c ", v" #b "\n"                                                                            \
+    "v_fma_f32 v0, v1, v" #b ", v2\n"                                                                                  \
+    "v_fma_f32 v0, v" #b ", v0, v5\n"                                                                                  \
+    "v_fma_f32 v3, v" #b ", v4, v5\n"                                                                                  \
+    "v_sqrt_f32 v0, v0\n"                                                                                              \
+    "v_add_f32 v0, v3, v0\n"                                                                                           \
+    "v_fma_f32 v3, -v0, v" #c ", 1.0\n"                                                                                \
+    "v_fma_f32 v0, v3, v" #c ", v" #c "\n"                                                                             \
+    "v_fma_f32 v" #a ", v" #b ", v0, v" #a "\n"                                                                        \
+    "v_add_f32 v" #a ", v" #a ", v0\n"
+
+// what makes an instruction mix slower than its parts: one fully dependent chain; a destination that
+// is none of the sources; the hit mix with its two quarter-rate instructions replaced by adds
+#define I_FMA_CHAIN(a, b, c) "v_fma_f32 v16, v16, v" #b ", v" #c "\n"
+#define I_FMA_DST(a, b, c) "v_fma_f32 v" #a ", v" #b ", v" #c ", v1\n"
+#define I_HIT_NO_TRANS(a, b, c)                                                                                        \
+    "v_add_f32 v" #b ", v" #c ", v" #b "\n"                                                                            \
+    "v_fma_f32 v0, v1, v" #b ", v2\n"                                                                                  \
+    "v_fma_f32 v0, v" #b ", v0, v5\n"                                                                                  \
+    "v_fma_f32 v3, v" #b ", v4, v5\n"                                                                                  \
+    "v_add_f32 v0, v0, v0\n"                                                                                           \
+    "v_add_f32 v0, v3, v0\n"                                                                                           \
+    "v_add_f32 v0, v0, v0\n"                                                                                           \
+    "v_fma_f32 v" #a ", v" #b ", v0, v" #a "\n"                                                                        \
+    "v_add_f32 v" #a ", v" #a ", v0\n"
+
+// one reciprocal among N independent fmas
+#define FMA_B(b, c) "v_fma_f32 v" #b ", v" #b ", v" #c ", v" #c "\n"
+#define I_RCP_FMA1(a, b, c) "v_rcp_f32 v" #a ", v" #a "\n" FMA_B(b, c)
+#define I_RCP_FMA7(a, b, c) "v_rcp_f32 v" #a ", v" #a "\n" FMA_B(b, c) FMA_B(b, c) FMA_B(b, c) FMA_B(b, c) FMA_B(b, c) FMA_B(b, c) FMA_B(b, c)
+#define I_RCP_FMA15(a, b, c) I_RCP_FMA7(a, b, c) FMA_B(b, c) FMA_B(b, c) FMA_B(b, c) FMA_B(b, c) FMA_B(b, c) FMA_B(b, c) FMA_B(b, c) FMA_B(b, c)
+// two reciprocals back to back among 6 fmas
+#define I_RCP2_FMA6(a, b, c) "v_rcp_f32 v" #a ", v" #a "\n v_rcp_f32 v" #c ", v" #c "\n" FMA_B(b, a) FMA_B(b, a) FMA_B(b, a) FMA_B(b, a) FMA_B(b, a) FMA_B(b, a)
+
 // the same nine instructions for four samples at a time, the quarter-rate ones back to back
 #define HIT_HEAD(u, d, h) "v_add_f32 v" #u ", v48, v" #u "\n v_fma_f32 v" #d ", v1, v" #u ", v2\n v_fma_f32 v" #d ", v" #u ", v" #d ", v5\n v_fma_f32 v" #h ", v" #u ", v4, v5\n"
 #define HIT_TAIL(u, d, a, b) "v_fma_f32 v" #a ", v" #u ", v" #d ", v" #a "\n v_add_f32 v" #b ", v" #b ", v" #d "\n"
@@ -160,6 +196,14 @@ PROBE_KERNEL(k_camera_sample, ROT16(I_SAMPLE))      // 16 samples x 8 instructio
 PROBE_KERNEL(k_rcp_fma3, X4(ROT16(I_RCP_FMA3)))     // 64 groups of 4 instructions
 PROBE_KERNEL(k_camera_hit, ROT16(I_HIT))            // 16 samples x 9 instructions = 144 per iteration
 PROBE_KERNEL(k_camera_hit_grouped, X4(HIT_GROUPED))
+PROBE_KERNEL(k_camera_hit_newton, ROT16(I_HIT_NEWTON))      // 16 samples x 10 instructions
+PROBE_KERNEL(k_rcp_fma1, X4(ROT16(I_RCP_FMA1)))
+PROBE_KERNEL(k_rcp_fma7, ROT16(I_RCP_FMA7))
+PROBE_KERNEL(k_rcp_fma15, ROT16(I_RCP_FMA15))
+PROBE_KERNEL(k_rcp2_fma6, ROT16(I_RCP2_FMA6))
+PROBE_KERNEL(k_fma_chain, X4(ROT16(I_FMA_CHAIN)))
+PROBE_KERNEL(k_fma_dst, X4(ROT16(I_FMA_DST)))
+PROBE_KERNEL(k_hit_no_trans, ROT16(I_HIT_NO_TRANS))
 
 // FP32 MFMA beside the vector unit: v_mfma_f32_32x32x2_f32 on four independent accumulator tiles
 // (a[0:63]), alone and with FILL v_fma_f32 issued after each -- does the vector unit keep its rate
@@ -280,6 +324,14 @@ int main() {
     run("rcp+3fma", k_rcp_fma3, 256, 7.0 / 4.0, cus, hz, d_out);
     run("camera_hit_mix", k_camera_hit, 144, 13.0 / 9.0, cus, hz, d_out);
     run("camera_hit_by_4", k_camera_hit_grouped, 144, 13.0 / 9.0, cus, hz, d_out);
+    run("camera_hit_newton", k_camera_hit_newton, 160, 16.0 / 10.0, cus, hz, d_out);
+    run("rcp+1fma", k_rcp_fma1, 128, 1.5, cus, hz, d_out);
+    run("rcp+7fma", k_rcp_fma7, 128, 15.0 / 8.0, cus, hz, d_out);
+    run("rcp+15fma", k_rcp_fma15, 256, 31.0 / 16.0, cus, hz, d_out);
+    run("2rcp+6fma", k_rcp2_fma6, 128, 14.0 / 8.0, cus, hz, d_out);
+    run("fma_one_chain", k_fma_chain, 64, 2, cus, hz, d_out);
+    run("fma_dst_not_src", k_fma_dst, 64, 2, cus, hz, d_out);
+    run("hit_mix_no_trans", k_hit_no_trans, 144, 13.0 / 9.0, cus, hz, d_out);
     // one unit = one v_mfma_f32_32x32x2_f32 (64 flop a lane) and the v_fma_f32 issued after it (2 flop a lane each)
     run("mfma_f32_32x32x2", k_mfma_f32, 16, 64, cus, hz, d_out);
     run("mfma+8fma", k_mfma_f32_8fma, 16, 64 + 16, cus, hz, d_out);
