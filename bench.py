@@ -53,6 +53,9 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3     # MI355X datasheet FP32 vector peak (256 CU 
 # Conversions, compares, 3-operand integer operations and anything with a scalar-register operand issue at
 # half that rate (4.22 clocks), v_rcp / v_sqrt / v_rsq at a quarter (8.24).
 VALU_FULL_RATE_MEASURED = 69.4e12
+CYCLES_FULL_RATE, CYCLES_HALF_RATE, CYCLES_QUARTER_RATE = 2.19, 4.22, 8.24
+SIMDS = 256 * 4
+SUSTAINED_CLOCK_HZ = 2.32e9
 HBM_PEAK_GBS = 8000.0
 COUNTERS_FILE = os.path.join(ROOT, "profiles", "r02_counters.json")
 KERNEL_SOURCES = ["raytracer_amd/csrc/hip_raytracer_kernels.hip", "raytracer_amd/csrc/rt_exact_math.h"]
@@ -82,13 +85,21 @@ def executed_work(doc, key, seconds_per_frame, share=1.0):
     w = (doc or {}).get("workloads", {}).get(key)
     if not w:
         return None
-    flop = valu = 0.0
+    flop = valu = slots = 0.0
     kernels = []
     for name, k in w["kernels"].items():
-        if "executed_fp32_flop_per_frame" not in k:
+        # kernels of the timed frame only: set-up's (the ring list, the row table) run once per backend
+        if "executed_fp32_flop_per_frame" not in k or k.get("dispatches_per_frame", 1.0) < 0.5:
             continue
         flop += k["executed_fp32_flop_per_frame"]
-        valu += k.get("SQ_INSTS_VALU", 0.0)
+        n = k.get("SQ_INSTS_VALU", 0.0)               # the file holds per-frame totals
+        valu += n
+        # issue cycles these instructions take at the rates each class reaches alone (tools/valu_peak.hip):
+        # quarter-rate transcendentals, half-rate conversions, everything else priced at full rate.  A lower
+        # bound: compares, scalar-register operands and a transcendental among other instructions cost more.
+        trans = k.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+        cvt = k.get("SQ_INSTS_VALU_CVT", 0.0)
+        slots += (n - trans - cvt) * CYCLES_FULL_RATE + trans * CYCLES_QUARTER_RATE + cvt * CYCLES_HALF_RATE
         kernels.append(name)
     if flop <= 0.0:
         return None
@@ -101,6 +112,7 @@ def executed_work(doc, key, seconds_per_frame, share=1.0):
         out["valu_wave_instructions_per_frame"] = valu
         out["valu_lane_ops_per_s"] = lane_ops
         out["valu_issue_vs_measured_full_rate"] = lane_ops / VALU_FULL_RATE_MEASURED
+        out["valu_issue_cycles_lower_bound_frac"] = slots / (SIMDS * SUSTAINED_CLOCK_HZ * seconds_per_frame)
     return out
 
 
@@ -126,6 +138,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true")
     ap.add_argument("--no-second-mode", action="store_true")
+    ap.add_argument("--walk-all", action="store_true",
+                    help="measurement aid: the timed run walks every sample of every pixel (AEHIP_FLAG_WALK_ALL)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     ap.add_argument("--watchdog", type=int, default=900,
                     help="seconds after which a rank dumps its Python stacks and exits (0 = off)")
@@ -244,9 +258,10 @@ def main():
 
     verified = {}
 
-    def timed_run(mode, steps, warmup):
-        """K steps of render-band + gather; returns (elapsed_s max over ranks, kernel_s max over ranks, stats)."""
-        flags = rt.FLAG_JITTER | (rt.FLAG_FAST if mode == "fast" else 0)
+    def timed_run(mode, steps, warmup, walk_all=False):
+        """K steps of render-band + gather; returns (elapsed_s max over ranks, kernel_s max over ranks, stats).
+        walk_all: every sample of every pixel goes through the sample loop (AEHIP_FLAG_WALK_ALL)."""
+        flags = rt.FLAG_JITTER | (rt.FLAG_FAST if mode == "fast" else 0) | (rt.FLAG_WALK_ALL if walk_all else 0)
         back = rt.HipRaytracer(None, device=dev_index)
         if not back.setup(WIDTH, HEIGHT, spp=args.spp, max_depth=args.depth, seed=1, flags=flags, pass_=rt.PASS_PATH,
                           **gather.band):
@@ -299,35 +314,38 @@ def main():
             whole.trace_device(ref.data_ptr(), None, stream)
             torch.cuda.synchronize()
             whole.close()
-            verified[mode] = bool(torch.equal(ref, gather.image))
-            if not verified[mode]:
+            verified[mode + ("_every_sample_walked" if walk_all else "")] = same = bool(torch.equal(ref, gather.image))
+            if not same:
                 ne = ref != gather.image
                 idx = ne.nonzero()[:6].tolist()
                 print("MISMATCH", mode, int(ne.sum()), idx, [(hex(ref[y, x].item() & 0xffffffff), hex(gather.image[y, x].item() & 0xffffffff)) for y, x in idx], file=sys.stderr, flush=True)
         return float(t[0]), float(t[1]), st
 
     other = "exact" if args.mode == "fast" else "fast"
-    elapsed, kernel_s, st = timed_run(args.mode, args.steps, args.warmup)
+    elapsed, kernel_s, st = timed_run(args.mode, args.steps, args.warmup, walk_all=args.walk_all)
     second = None if args.no_second_mode else timed_run(other, max(2, args.steps // 2), 1)
+    # the same frames with every sample of every pixel walked: what the pixels decided by bounds save
+    walked = {} if args.no_second_mode else {m: timed_run(m, max(2, args.steps // 4), 1, walk_all=True) for m in (args.mode, other)}
 
     if rank == 0:
         paths_total = WIDTH * HEIGHT * args.spp
         counters, counters_error = load_counters()
         headline = args.spp == 1024 and args.depth == 8          # the workload the counters were collected on
 
-        def roofline_of(mode, seconds, stats):
+        def roofline_of(mode, seconds, stats, walked=False):
             """Executed FP32 work (counters) over this run's kernel time; the reference formulas' flops beside it."""
             # every rank renders 1/world of the frame, the same mix of rows (tiles dealt round-robin)
             algorithmic = frame_flops(paths_total / world, WIDTH * HEIGHT / world) / seconds / 1e12
-            ex = executed_work(counters, f"headline_{mode}", seconds, 1.0 / world) if headline else None
+            key = f"headline_{mode}" + ("_walked" if walked else "")
+            ex = executed_work(counters, key, seconds, 1.0 / world) if headline else None
             r = {"bound": "valu_fp32", "achieved": ex["tflops"] if ex else None, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": ex["tflops"] / FP32_VECTOR_PEAK_TFLOPS if ex else None, "traffic": None,
-                 "kernel": "camera_hybrid_kernel" if mode == "fast" else "camera_kernel",
+                 "kernel": "camera_hybrid_kernel" if mode == "fast" else "camera_kernel", "counters": key,
                  "algorithmic_tflops": algorithmic, "vgprs": stats.vgprs, "lds_bytes": stats.lds_bytes}
             if ex:
                 r["executed"] = ex
                 r["work_reduction"] = algorithmic / ex["tflops"]
-                k = counters["workloads"][f"headline_{mode}"]["kernels"].get(r["kernel"], {})
+                k = counters["workloads"][key]["kernels"].get(r["kernel"], {})
                 if "WRITE_SIZE" in k and "FETCH_SIZE" in k:
                     # HBM bytes per launch: WRITE_SIZE in KiB; FETCH_SIZE in KiB, x2 on gfx950 (it under-reports wide reads)
                     r["traffic"] = int((k["WRITE_SIZE"] * 1024 + k["FETCH_SIZE"] * 2048) / world)
@@ -363,8 +381,10 @@ def main():
             "device": device_facts(torch, dev_index),
             "gathered_frame_equals_single_gpu_frame": verified,
             "rays_per_s": paths_total / (elapsed / args.steps),
-            "roofline": roofline_of(args.mode, kernel_s, st),
+            "roofline": roofline_of(args.mode, kernel_s, st, args.walk_all),
         }
+        if args.walk_all:
+            line["config"]["workload"] += ", every sample of every pixel walked (AEHIP_FLAG_WALK_ALL)"
         line["roofline"]["measured_full_rate_valu_lane_ops_per_s"] = VALU_FULL_RATE_MEASURED
         if second is not None:
             e2, k2, st2 = second
@@ -373,6 +393,15 @@ def main():
                 "value": paths_total / (e2 / steps2) / 1e6, "unit": "Mpaths/s", "ms_per_step": e2 / steps2 * 1e3,
                 "kernel_ms": k2 * 1e3, "steps": steps2, "roofline": roofline_of(other, k2, st2),
             }
+        if walked:
+            line["every_sample_walked"] = {
+                m: {"value": paths_total / (e / max(2, args.steps // 4)) / 1e6, "unit": "Mpaths/s",
+                    "ms_per_step": e / max(2, args.steps // 4) * 1e3, "kernel_ms": k * 1e3,
+                    "roofline": roofline_of(m, k, wst, True)}
+                for m, (e, k, wst) in walked.items()}
+            line["every_sample_walked"]["note"] = (
+                "AEHIP_FLAG_WALK_ALL: no pixel is decided from bounds over its sample positions; exact build: the same "
+                "image bit for bit (tests/test_gpu_parity.py)")
         if world == 1 and not args.no_aux:
             line["aux"] = aux_measurements(rt, torch, stream, counters)
         if world == 1 and not args.no_cpu_baseline:

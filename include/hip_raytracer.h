@@ -45,9 +45,14 @@ enum {
                                     IEEE fp32 in the reference's operation order             */
     AEHIP_FLAG_COUNT_RAYS = 4u,  /* count ray segments and lane slots on the device
                                     (aehip_stats.rays, aehip_stats.lane_slots)               */
-    AEHIP_FLAG_NO_REGEN   = 8u   /* measurement aid: a lane whose path ended waits until every
+    AEHIP_FLAG_NO_REGEN   = 8u,  /* measurement aid: a lane whose path ended waits until every
                                     lane of its wave is done before starting its next sample
                                     (the image is unchanged; only lane utilisation differs)  */
+    AEHIP_FLAG_WALK_ALL   = 16u  /* measurement aid: the single-sphere camera pass walks every
+                                    sample of every pixel instead of deciding, from bounds over
+                                    the pixel's sample positions, the pixels whose samples all
+                                    miss (and, fast build, all hit).  Exact build: the image is
+                                    unchanged bit for bit; fast build: within its tolerance   */
 };
 
 enum {

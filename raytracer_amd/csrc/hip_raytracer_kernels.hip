@@ -1515,6 +1515,7 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                     if(cc.near_root_only != 0u && pc.may_hit && pc.well_conditioned)
                         cls |= pc.faces_sphere ? kSureHit : kCulled;       // behind the camera: no root counts
                 }
+                if(vc.flags & AEHIP_FLAG_WALK_ALL) cls &= kListed;      // every pixel through the general loop
                 s_class[strip][lane] = cls;
                 const bool strip_work = __ballot(valid && (cls & (kCulled | kListed)) == 0u) != 0ull;
                 if(lane == 0u) s_strip_work[strip] = strip_work ? 1u : 0u;
@@ -2251,7 +2252,7 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
     do {                                                                                                               \
         func = reinterpret_cast<const void *>(camera_kernel<E, O, F, A>);                                              \
         hipLaunchKernelGGL((camera_kernel<E, O, F, A>), grid, dim3(kBlock), 0, stream, vc, b->cc, split_log2,          \
-                           b->d_geom, b->d_sample_terms, argb_dev, rgba, (E) && (O) && (F) ? b->d_row_miss : nullptr); \
+                           b->d_geom, b->d_sample_terms, argb_dev, rgba, (E) && (O) && (F) && !(vc.flags & AEHIP_FLAG_WALK_ALL) ? b->d_row_miss : nullptr); \
     } while(0)
         // one ray per sample, whether the sample loop walks it or the pixel's bounds decide it; a
         // strip's 64 lanes are counted for each of its samples

@@ -45,7 +45,7 @@ def render_device(width, height, want_rgba=True, **kw):
     import torch
 
     flags = (rt.FLAG_JITTER if kw.pop("jitter", False) else 0) | (rt.FLAG_FAST if kw.pop("fast", False) else 0) \
-        | (rt.FLAG_COUNT_RAYS if kw.pop("count_rays", False) else 0)
+        | (rt.FLAG_COUNT_RAYS if kw.pop("count_rays", False) else 0) | (rt.FLAG_WALK_ALL if kw.pop("walk_all", False) else 0)
     row_begin = kw.pop("row_begin", 0)
     row_count = kw.pop("row_count", 0)
     rows = row_count if row_count else height - row_begin
@@ -287,6 +287,38 @@ def test_benchmark_size_path_traced_images_against_the_cpu_image_and_the_exact_b
         _, fast, _ = render_device(w, h, jitter=True, spheres=sph, fast=True, **kw)
         _, exact, _ = render_device(w, h, jitter=True, spheres=sph, **kw)
         assert psnr(fast[..., :3], exact[..., :3]) >= bound
+
+
+@pytest.mark.parametrize("view", ["default", "far_small", "large_near", "off_axis_camera", "grazing", "behind", "inside"])
+def test_pixels_decided_by_bounds_equal_pixels_walked_sample_by_sample(view):
+    """The single-sphere camera pass decides from bounds over a pixel's sample positions the pixels
+    whose samples all miss (both builds) or all hit (fast build) and walks the samples of the
+    others; AEHIP_FLAG_WALK_ALL walks every sample of every pixel.  Exact build: the two images
+    are the same bits (a pixel decided to miss holds the row's background summed in sample order).
+    Fast build: the hit loop writes the near root another way, so colours agree to rounding."""
+    center, radius, cam = {"default": ((0.0, 0.0, -1.0), 0.5, (0.0, 0.0, 0.0)),
+                           "far_small": ((0.3, 0.1, -6.0), 0.5, (0.0, 0.0, 1.0)),
+                           "large_near": ((0.5, -0.2, -3.0), 2.5, (0.0, 0.0, 1.0)),
+                           "off_axis_camera": ((0.0, 0.0, -2.0), 1.0, (0.6, 0.3, 1.4)),
+                           "grazing": ((1.0, 0.0, -2.0), 1.0, (0.0, 0.0, 1.0)),
+                           "behind": ((0.2, 0.1, 3.0), 1.0, (0.0, 0.0, 1.0)),
+                           "inside": ((0.0, 0.0, 0.5), 2.0, (0.0, 0.0, 1.0))}[view]
+    s = np.zeros(1, dtype=rt.SPHERE_DTYPE)
+    s["center"][0] = center
+    s["radius"] = radius
+    s["material"] = rt.MAT_NORMAL
+    kw = dict(spheres=s, spp=70, max_depth=3, seed=5, jitter=True)
+    if view != "default":
+        kw["cam"] = cam
+    w, h = 640, 360
+    argb, rgba, _ = render_device(w, h, **kw)
+    argb_all, rgba_all, _ = render_device(w, h, walk_all=True, **kw)
+    np.testing.assert_array_equal(rgba.view(np.uint32), rgba_all.view(np.uint32))
+    np.testing.assert_array_equal(argb, argb_all)
+    _, fast, _ = render_device(w, h, fast=True, **kw)
+    _, fast_all, _ = render_device(w, h, fast=True, walk_all=True, **kw)
+    assert float(np.abs(fast - fast_all).max()) <= 2e-6
+    assert float(np.abs(fast[..., :3] - rgba[..., :3]).max()) <= 1e-5
 
 
 def test_fast_default_scene_jittered_matches_exact_closely():
