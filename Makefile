@@ -5,7 +5,7 @@
 HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 # -ffp-contract=off: fusion happens only where the source asks for it (exact vs fast paths)
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wextra -Iinclude
 HOSTCXX  ?= /opt/rocm/lib/llvm/bin/clang++
 # -ffp-contract=off: the software backend evaluates IEEE fp32 in source order, like the reference's build (build.sh:7-31)
 HOSTFLAGS := -std=c++20 -O2 -ffp-contract=off -Wall -Wextra -pedantic -Werror -Iinclude -Iraytracer_amd/host

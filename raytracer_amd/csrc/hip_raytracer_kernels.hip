@@ -1368,7 +1368,19 @@ struct pixel_class {
     bool may_hit;               // false: every sample misses, by more than the screening margin
     bool well_conditioned;      // every sample hits, with conditioning value q >= kExactBelowQ
     bool faces_sphere;          // h = draw.oc > 0 at the pixel (h keeps its sign over a pixel whose samples all hit)
+    bool newton_ok;             // the hit distance may be carried from cell to cell by one Newton step (kNewtonTolerance)
 };
+
+// The fast build's hit loop carries the hit distance t of the unnormalised ray along a row of
+// cells: from the previous cell's t one Newton step on dd t*t - 2 h t + c = 0, whose derivative
+// at the near root is -2 sqrt(disc); 1 / sqrt(disc) is expanded to first order about the middle of
+// the row.  No square root and no reciprocal per sample (quarter-rate instructions that cost a mix of
+// full-rate ones 13-15 clocks each, tools/valu_peak.hip).  With dt the distance's change from
+// one cell to the next and eps the relative error of the expanded 1 / sqrt(disc), a step leaves
+// t within eps dt + dt*dt dd / (2 sqrt(disc)) of the root.  classify_pixel bounds that over the
+// pixel from the discriminant's gradient and admits the pixel when the colour moves by less
+// than this (other pixels take the loop that computes every root from scratch).
+constexpr float kNewtonTolerance = 1e-6f;
 
 __device__ __forceinline__ pixel_class classify_pixel(const view_consts &vc, const camera_consts &cc, uint32_t x, uint32_t y) {
     const bool jitter = (vc.flags & AEHIP_FLAG_JITTER) != 0;
@@ -1380,6 +1392,7 @@ __device__ __forceinline__ pixel_class classify_pixel(const view_consts &vc, con
     const float eu = jitter ? vc.psx : 0.0f, ev = jitter ? vc.psy : 0.0f;
     const float dz = 0.0f - vc.cam[2];
     float disc_min = 3.402823466e+38f, disc_max = -3.402823466e+38f, big_max = 0.0f, h_corner = 0.0f;
+    float h_min = 3.402823466e+38f, dd_max = 0.0f, slope_max = 0.0f;
 #pragma unroll
     for(int k = 0; k < 4; k++) {
         const float u = u0 + ((k & 1) ? eu : 0.0f), v = v0 + ((k & 2) ? ev : 0.0f);
@@ -1390,6 +1403,12 @@ __device__ __forceinline__ pixel_class classify_pixel(const view_consts &vc, con
         disc_max = fmaxf(disc_max, disc);
         big_max = fmaxf(big_max, __builtin_fmaf(dd, cc.magnitude, h * h));
         if(k == 0) h_corner = h;
+        h_min = fminf(h_min, h);
+        dd_max = fmaxf(dd_max, dd);
+        // d disc / d u, linear in (u, v): largest at a corner
+        slope_max = fmaxf(slope_max, fabsf(__builtin_fmaf(2.0f * cc.q_uu, u, __builtin_fmaf(cc.q_uv, v, cc.q_u))));
+        // (and d disc / d v, in units of the step along u: the pixel is psy tall and psx wide)
+        slope_max = fmaxf(slope_max, fabsf(__builtin_fmaf(2.0f * cc.q_vv, v, __builtin_fmaf(cc.q_uv, u, cc.q_v))) * (vc.psy / vc.psx));
     }
     // smallest dd over the rectangle: each coordinate at its smallest magnitude
     const float ua = (u0 <= 0.0f && u0 + eu >= 0.0f) ? 0.0f : fminf(fabsf(u0), fabsf(u0 + eu));
@@ -1405,7 +1424,53 @@ __device__ __forceinline__ pixel_class classify_pixel(const view_consts &vc, con
     // q >= kExactBelowQ for every sample of the pixel, with 5 % to spare; false for NaN / inf: such pixels are listed
     pc.well_conditioned = (disc_min - pad) * (dd_min * cc.radius2) >= (kExactBelowQ * 1.05f) * (big_max * big_max);
     pc.faces_sphere = h_corner > 0.0f;
+    // Newton's step along a row of cells (see kNewtonTolerance): the widest cell of the pixel's grid
+    // is a ragged last row's
+    const uint32_t last_row_cells = vc.spp - (((vc.spp - 1u) >> vc.row_bits) << vc.row_bits);
+    const float du = jitter ? vc.psx / static_cast<float>(min(1u << vc.row_bits, last_row_cells)) : 0.0f;
+    const float s_min = __builtin_sqrtf(fmaxf(disc_min - pad, 0.0f));
+    const float ds = slope_max * du / (2.0f * s_min);                   // change of sqrt(disc) over a cell
+    const float t_max = cc.c / h_min;                                    // t = c / (h + sqrt(disc))
+    const float u_abs = fmaxf(fabsf(u0), fabsf(u0 + eu));
+    const float dt = (fabsf(cc.oc[0]) * du + ds + 2.0f * t_max * u_abs * du) / dd_min;
+    // 1 / sqrt(disc) comes from its first-order expansion about the pixel's centre.  With
+    // g = the relative change of disc across the pixel (2 cells ds / s_min along either axis;
+    // slope_max covers both) the second-order term left out is 3/8 (g/2)^2 of it at an edge's
+    // middle, twice that in a corner: under g*g / 4.  A row's first T comes from such an expansion
+    // too (left out: about (t / (h + sqrt(disc))) (cells ds)^2 / (8 sqrt(disc)) an axis, under
+    // g cells dt / 4), then takes a step like the others.
+    const float cells = static_cast<float>(1u << vc.row_bits);
+    const float pixel_change = 2.0f * cells * ds / s_min;
+    const float eps = 0.25f * pixel_change * pixel_change;
+    const float start = dt + 0.25f * pixel_change * cells * dt;
+    const float t_error = 2.0f * (eps * start + start * start * dd_max / (2.0f * s_min));
+    // colour = draw * (shade_scale * t) + constant; false for NaN (s_min = 0, h_min <= 0 give inf or a negative bound)
+    pc.newton_ok = h_min > 0.0f && cc.c > 0.0f && eps <= 0.05f && cc.shade_scale * __builtin_sqrtf(dd_max) * t_error <= kNewtonTolerance;
     return pc;
+}
+
+// True when no sample of the pixels [x0, x1) x [y0, y1) (image rows) can hit: the corner bound of
+// classify_pixel over the whole rectangle, with twice its padding -- so every pixel inside is
+// one classify_pixel would call a miss as well, and none of them is an ill-conditioned one.
+__device__ __forceinline__ bool rectangle_misses(const view_consts &vc, const camera_consts &cc, uint32_t x0, uint32_t x1, uint32_t y0,
+                                                 uint32_t y1) {
+    const bool jitter = (vc.flags & AEHIP_FLAG_JITTER) != 0;
+    const float shift = jitter ? 0.0f : 0.5f;
+    const float u0 = __builtin_fmaf(static_cast<float>(x0) + shift, vc.psx, -(vc.vw_half + vc.cam[0]));
+    const float v0 = __builtin_fmaf(static_cast<float>(y0) + shift, vc.psy, -(vc.vh_half + vc.cam[1]));
+    const float eu = static_cast<float>(x1 - x0 - (jitter ? 0u : 1u)) * vc.psx, ev = static_cast<float>(y1 - y0 - (jitter ? 0u : 1u)) * vc.psy;
+    const float dz = 0.0f - vc.cam[2];
+    float disc_max = -3.402823466e+38f, big_max = 0.0f;
+#pragma unroll
+    for(int k = 0; k < 4; k++) {
+        const float u = u0 + ((k & 1) ? eu : 0.0f), v = v0 + ((k & 2) ? ev : 0.0f);
+        const float dd = __builtin_fmaf(v, v, __builtin_fmaf(u, u, dz * dz));
+        const float h = __builtin_fmaf(v, cc.oc[1], __builtin_fmaf(u, cc.oc[0], dz * cc.oc[2]));
+        disc_max = fmaxf(disc_max, __builtin_fmaf(-dd, cc.c, h * h));
+        big_max = fmaxf(big_max, __builtin_fmaf(dd, cc.magnitude, h * h));
+    }
+    const float pad = fabsf(cc.q_uu) * eu * eu + fabsf(cc.q_uv) * eu * ev + fabsf(cc.q_vv) * ev * ev + 1e-5f * big_max;
+    return disc_max + 2.0f * pad < -(kScreenMargin * 1.01f) * big_max;       // false for NaN
 }
 
 __device__ __forceinline__ bool pixel_needs_reference(const view_consts &vc, const camera_consts &cc, uint32_t x, uint32_t y) {
@@ -1437,6 +1502,9 @@ __global__ __launch_bounds__(256) void ring_pixels_kernel(view_consts vc, camera
     }
 }
 
+// camera_body's split_and_tile argument: waves per strip (log2) in the low byte, and
+constexpr uint32_t kCameraTiled = 0x100u;      // a workgroup owns a 16x16 tile and renders its strips in rounds
+
 // ------------------------------------------------------------------------------------------
 // camera pass: the path pass specialised for scenes in which every surface ends the path
 // (all materials NORMAL -- the reference's scene).  Every path is one segment from the camera,
@@ -1461,7 +1529,7 @@ __global__ __launch_bounds__(256) void ring_pixels_kernel(view_consts vc, camera
 // SKIP_LISTED: pixels that pixel_needs_reference() are left out (the same launch renders them
 // from the list with the exact build's arithmetic, see camera_hybrid_kernel).
 template <bool EXACT, bool ONE, bool FOLD, bool AXIAL, bool SKIP_LISTED, bool FAST_AFTER_DISC = false>
-__device__ __forceinline__ void camera_body(const view_consts &vc, const camera_consts &cc, uint32_t split_log2,
+__device__ __forceinline__ void camera_body(const view_consts &vc, const camera_consts &cc, uint32_t split_and_tile,
                                             const float4 *__restrict__ geom, const uint32_t *__restrict__ sample_terms,
                                             uint32_t *__restrict__ argb, float4 *__restrict__ rgba, uint32_t group_x,
                                             uint32_t group_y, const uint32_t *__restrict__ pixel_list, uint32_t list_count,
@@ -1474,66 +1542,95 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
 
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+    const uint32_t split_log2 = split_and_tile & 0xffu;
     const uint32_t split = 1u << split_log2;                    // waves per strip
-    const uint32_t strip = wave >> split_log2;                  // strip of the workgroup
     const uint32_t part = wave & (split - 1u);                  // this wave's place among the strip's waves
-    uint32_t x = group_x * kTileW + (lane & 15u);
-    uint32_t row = (group_y * (kWaves >> split_log2) + strip) * 4u + (lane >> 4);
-    bool valid = (x < vc.width) && (row < vc.row_count);
-    if(pixel_list) {
-        const uint32_t entry = (group_x * (kWaves >> split_log2) + strip) * 64u + lane;
-        valid = entry < list_count;
-        const uint32_t packed = valid ? pixel_list[entry] : 0u;
-        x = packed & 0xffffu;
-        row = (packed >> 16) - list_row_bias;      // entries hold rows of the whole band; a launch may render part of it
-    }
-    const uint32_t y = image_row(vc, row);
+    const uint32_t strips_per_round = kWaves >> split_log2;     // strips the workgroup renders side by side
+    // One sphere, rectangle launch, kCameraTiled: the workgroup owns a tile of kWaves strips (16x16
+    // pixels) and renders them in `split` rounds of strips_per_round.  A tile around which nothing
+    // is hit then costs one short workgroup of busy waves instead of `split` workgroups with one
+    // busy wave each; a tile full of hits keeps its waves `split` times as long.
+    const bool tiled = ONE && pixel_list == nullptr && (split_and_tile & kCameraTiled) != 0u;
+    const uint32_t rounds = tiled ? split : 1u;
+    const uint32_t strips_per_group = tiled ? kWaves : strips_per_round;
+    const f3 cam = {vc.cam[0], vc.cam[1], vc.cam[2]};
+    const uint32_t n_spheres = ONE ? 1u : vc.n_spheres;
+    const uint32_t nblocks = (vc.spp + AEHIP_SAMPLE_BLOCK - 1u) / AEHIP_SAMPLE_BLOCK;
+
+    auto store_pixel = [&](uint32_t px, uint32_t prow, f3 total) {
+        const float n = static_cast<float>(vc.spp);
+        // the mean is a true division in both builds (once per pixel): an approximate reciprocal
+        // would turn a row of exact 1.0 samples into 0.99999994 and the truncating pack into 254
+        const float r = clamp01(total.x / n);
+        const float g = clamp01(total.y / n);
+        const float b = clamp01(total.z / n);
+        const size_t idx = static_cast<size_t>(prow) * vc.width + px;
+        argb[idx] = pack_argb32(r, g, b);
+        if(rgba) rgba[idx] = make_float4(r, g, b, 1.0f);
+    };
+    // a pixel all of whose samples miss: the row background summed spp times -- in the fast build a
+    // product, in the exact build the sum in sample order that set-up tabulated per image row
+    auto all_miss_total = [&](uint32_t py) {
+        if constexpr(EXACT) {
+            const float4 t = row_miss[py];
+            return f3{t.x, t.y, t.z};
+        } else {
+            const f3 bg_row = row_background<EXACT>(vc, py);
+            const float misses = static_cast<float>(vc.spp);
+            return f3{misses * bg_row.x, misses * bg_row.y, misses * bg_row.z};
+        }
+    };
+
     // One sphere: bounds over the pixel's sample positions (classify_pixel) say of all but the
     // pixels along the silhouette that every sample misses or that every sample hits.
-    //  - every sample misses: the pixel stays out of the sample loop.  Its value is the row
-    //    background summed spp times -- in the fast build a product, in the exact build the sum in
-    //    sample order that set-up tabulated per image row (row_miss; without the table the exact
-    //    build culls nothing).
-    //  - every sample hits, well conditioned, near root (fast build): the hit loop, which neither
+    //  - every sample misses: the pixel stays out of the sample loop (all_miss_total; without
+    //    set-up's table the exact build culls nothing).
+    //  - every sample hits, well conditioned, near root (fast build): a hit loop, which neither
     //    tests nor branches.
     // Everything else goes through the general loop.
-    // The waves that share a strip share its pixels: the strip's first wave classifies, the
-    // others read the result (a class costs about a hundred vector instructions).
-    bool culled = false, sure_hit = false;
-    bool group_idle = false;            // no pixel of the workgroup is in the sample loop
+    // A strip is classified by one wave (a class costs about a hundred vector instructions): wave
+    // w takes strip w of a tile, otherwise the strip's first wave; it writes the strip at once
+    // when none of its pixels needs the sample loop; the classes reach the waves that render the
+    // strip through LDS.  Before that every wave tests the workgroup's whole rectangle: around
+    // most of the frame nothing can be hit, and the workgroup ends without classes or a barrier.
+    constexpr uint32_t kCulled = 1u, kSureHit = 2u, kListed = 4u, kNewton = 8u;
+    __shared__ uint32_t s_class[ONE ? kWaves : 1][64];
+    __shared__ uint32_t s_strip_work[kWaves];
+    bool classified = false;
     if constexpr(ONE) {
-        if(!pixel_list && (!EXACT || row_miss != nullptr)) {
-            constexpr uint32_t kCulled = 1u, kSureHit = 2u, kListed = 4u;
-            __shared__ uint32_t s_class[kWaves][64];
-            __shared__ uint32_t s_strip_work[kWaves];
+        if(pixel_list == nullptr && (!EXACT || row_miss != nullptr)) {
+            classified = true;
+            const bool classifier = tiled || part == 0u;
+            const uint32_t cstrip = tiled ? wave : wave >> split_log2;
+            const uint32_t cx = group_x * kTileW + (lane & 15u);
+            const uint32_t crow = (group_y * strips_per_group + cstrip) * 4u + (lane >> 4);
+            const bool cvalid = classifier && (cx < vc.width) && (crow < vc.row_count);
+            const uint32_t cy = image_row(vc, crow);
+            const uint32_t grow0 = group_y * strips_per_group * 4u;
+            const uint32_t grow1 = min(grow0 + strips_per_group * 4u, vc.row_count);       // the grid has no workgroup past the last row
+            if(!(vc.flags & AEHIP_FLAG_WALK_ALL) &&
+               rectangle_misses(vc, cc, group_x * kTileW, min(group_x * kTileW + kTileW, vc.width), image_row(vc, grow0), image_row(vc, grow1 - 1u) + 1u)) {
+                if(cvalid) store_pixel(cx, crow, all_miss_total(cy));
+                return;
+            }
             uint32_t cls = 0;
-            if(part == 0u) {
-                const pixel_class pc = classify_pixel(vc, cc, x, y);
+            if(classifier) {
+                const pixel_class pc = classify_pixel(vc, cc, cx, cy);
                 if(SKIP_LISTED && pc.may_hit && !pc.well_conditioned) cls |= kListed;
                 if(!pc.may_hit) cls |= kCulled;
                 if constexpr(!EXACT) {
                     if(cc.near_root_only != 0u && pc.may_hit && pc.well_conditioned)
-                        cls |= pc.faces_sphere ? kSureHit : kCulled;       // behind the camera: no root counts
+                        cls |= pc.faces_sphere ? (pc.newton_ok ? kNewton : kSureHit) : kCulled;    // behind the camera: no root counts
                 }
                 if(vc.flags & AEHIP_FLAG_WALK_ALL) cls &= kListed;      // every pixel through the general loop
-                s_class[strip][lane] = cls;
-                const bool strip_work = __ballot(valid && (cls & (kCulled | kListed)) == 0u) != 0ull;
-                if(lane == 0u) s_strip_work[strip] = strip_work ? 1u : 0u;
+                s_class[cstrip][lane] = cls;
+                const bool strip_work = __ballot(cvalid && (cls & (kCulled | kListed)) == 0u) != 0ull;
+                if(lane == 0u) s_strip_work[cstrip] = strip_work ? 1u : 0u;
+                if(!strip_work && cvalid && (cls & kListed) == 0u) store_pixel(cx, crow, all_miss_total(cy));
             }
             __syncthreads();
-            if(part != 0u) cls = s_class[strip][lane];
-            uint32_t any = 0;
-            for(uint32_t i = 0; i < (kWaves >> split_log2); i++) any |= s_strip_work[i];
-            group_idle = any == 0u;
-            valid = valid && (cls & kListed) == 0u;
-            culled = (cls & kCulled) != 0u;
-            sure_hit = (cls & kSureHit) != 0u;
         }
     }
-    const bool work = valid && !culled;
-    const f3 cam = {vc.cam[0], vc.cam[1], vc.cam[2]};
-    const uint32_t n_spheres = ONE ? 1u : vc.n_spheres;
-    const uint32_t nblocks = (vc.spp + AEHIP_SAMPLE_BLOCK - 1u) / AEHIP_SAMPLE_BLOCK;
 
     if constexpr(!ONE) {
         for(uint32_t i = tid; i < n_spheres; i += kBlock) {
@@ -1546,198 +1643,493 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
         __syncthreads();
     }
 
-    (void)sample_terms;     // every path of this pass ends at its first hit: no path ever draws a random number
-    const f3 bg = row_background<EXACT>(vc, y);
-    const uint32_t pix_term = pixel_term(vc.seed_hash, y * vc.width + x);
-    // Sample positions (see sample_offset): the pixel's samples sit on a grid, the cell index is
-    // the same in every lane, and a row of cells shares its vertical position.  So the sample loop
-    // runs row by row: what depends on the row (the ray's v coordinate and everything built from
-    // it) is worked out once per row, and going to the next cell is one vector add.
-    const bool jitter = (vc.flags & AEHIP_FLAG_JITTER) != 0;
-    const pixel_offset off = offset_of_pixel(pix_term);
-    const float xf = static_cast<float>(x), yf = static_cast<float>(y);
-    const float dz = 0.0f - cam.z;
-    const float dz2 = dz * dz;
-    const uint32_t row_cells = 1u << vc.row_bits;
-    // the ray's viewport offsets of a sample at (jx, jy) in the pixel, folded into one fma per coordinate:
-    // u = ux0 + psx * jx, v = uy0 + psy * jy
-    const float ux0 = __builtin_fmaf(xf, vc.psx, -(vc.vw_half + cam.x));
-    const float uy0 = __builtin_fmaf(yf, vc.psy, -(vc.vh_half + cam.y));
-
-    // One sphere: the discriminant h*h - dd*c of the unnormalised ray (u, v, dz) is a quadratic in
-    // (u, v) with the coefficients of camera_consts; along a row of cells v is fixed and
-    //   disc(u) = u * (q_uu * u + B) + C,   B = q_uv v + q_u,   C = v (q_vv v + q_v) + q_0:
-    // two fmas per sample.  Every term of the expansion is at most a few times
-    // M = h*h + dd*(oc.oc + r*r), so this evaluation is, like the direct one, within a few dozen
-    // unit roundoffs of M of the real value.  The exact build screens with it: its constant term
-    // takes the margin times an upper bound of M over the pixel (all terms taken positive at the
-    // corner of the pixel farthest from the axes).
-    float screen_margin = 0.0f;
-    if constexpr(ONE && EXACT) {
-        const float ua = fmaxf(fabsf(ux0), fabsf(ux0 + vc.psx));
-        const float va = fmaxf(fabsf(uy0), fabsf(uy0 + vc.psy));
-        const float hmax = __builtin_fmaf(ua, fabsf(cc.oc[0]), __builtin_fmaf(va, fabsf(cc.oc[1]), fabsf(dz * cc.oc[2])));
-        const float ddmax = __builtin_fmaf(ua, ua, __builtin_fmaf(va, va, dz2));
-        screen_margin = (kScreenMargin * 1.001f) * __builtin_fmaf(ddmax, cc.magnitude, hmax * hmax);
-    }
-
-    // a row of cells inside the sample range [s, s_end): which cells, and where they sit
-    struct cell_row {
-        uint32_t count;         // cells of the row inside the range
-        float first;            // index of the first of them, as a float
-        float inv_cells;        // 1 / cells in the whole row (exact for a full row)
-        float jy;               // vertical position of the row's samples in the pixel
-    };
-    auto row_at = [&](uint32_t s, uint32_t s_end) {
-        cell_row cr;
-        if(!jitter) {           // every sample at the pixel centre: one "row" for the whole range
-            cr.count = s_end - s;
-            cr.first = 0.0f;
-            cr.inv_cells = 0.0f;
-            cr.jy = 0.5f;
-            return cr;
+    for(uint32_t round = 0; round < rounds; round++) {
+        const uint32_t strip = round * strips_per_round + (wave >> split_log2);     // strip of the workgroup
+        uint32_t x = group_x * kTileW + (lane & 15u);
+        uint32_t row = (group_y * strips_per_group + strip) * 4u + (lane >> 4);
+        bool valid = (x < vc.width) && (row < vc.row_count);
+        if(pixel_list) {
+            const uint32_t entry = (group_x * strips_per_round + strip) * 64u + lane;
+            valid = entry < list_count;
+            const uint32_t packed = valid ? pixel_list[entry] : 0u;
+            x = packed & 0xffffu;
+            row = (packed >> 16) - list_row_bias;      // entries hold rows of the whole band; a launch may render part of it
         }
-        const uint32_t r = s >> vc.row_bits, n_r = cells_in_row(vc, r);
-        cr.count = min(s_end, (r << vc.row_bits) + n_r) - s;
-        cr.first = static_cast<float>(s & (row_cells - 1u));
-        // (a power of two in all rows but a ragged last one: its reciprocal comes from the exponent,
-        // in the scalar unit, instead of a division)
-        cr.inv_cells = (n_r & (n_r - 1u)) == 0u ? __uint_as_float((127u - static_cast<uint32_t>(__builtin_ctz(n_r))) << 23)
-                                                : 1.0f / static_cast<float>(n_r);
-        cr.jy = (static_cast<float>(r << vc.row_bits) + off.ry * static_cast<float>(n_r)) * vc.inv_spp;
-        return cr;
-    };
+        const uint32_t y = image_row(vc, row);
+        bool culled = false, sure_hit = false, newton = false;
+        if constexpr(ONE) {
+            if(classified) {
+                // a round none of whose strips has a pixel in the sample loop (their classifiers wrote them)
+                uint32_t any = 0;
+                for(uint32_t i = 0; i < strips_per_round; i++) any |= s_strip_work[round * strips_per_round + i];
+                if(any == 0u) continue;
+                const uint32_t cls = s_class[strip][lane];
+                valid = valid && (cls & kListed) == 0u && s_strip_work[strip] != 0u;
+                culled = (cls & kCulled) != 0u;
+                sure_hit = (cls & kSureHit) != 0u;
+                newton = (cls & kNewton) != 0u;
+            }
+        }
+        const bool work = valid && !culled;
 
-    f3 sum = {0.0f, 0.0f, 0.0f};
+        (void)sample_terms;     // every path of this pass ends at its first hit: no path ever draws a random number
+        const f3 bg = row_background<EXACT>(vc, y);
+        const uint32_t pix_term = pixel_term(vc.seed_hash, y * vc.width + x);
+        // Sample positions (see sample_offset): the pixel's samples sit on a grid, the cell index is
+        // the same in every lane, and a row of cells shares its vertical position.  So the sample loop
+        // runs row by row: what depends on the row (the ray's v coordinate and everything built from
+        // it) is worked out once per row, and going to the next cell is one vector add.
+        const bool jitter = (vc.flags & AEHIP_FLAG_JITTER) != 0;
+        const pixel_offset off = offset_of_pixel(pix_term);
+        const float xf = static_cast<float>(x), yf = static_cast<float>(y);
+        const float dz = 0.0f - cam.z;
+        const float dz2 = dz * dz;
+        const uint32_t row_cells = 1u << vc.row_bits;
+        // the ray's viewport offsets of a sample at (jx, jy) in the pixel, folded into one fma per coordinate:
+        // u = ux0 + psx * jx, v = uy0 + psy * jy
+        const float ux0 = __builtin_fmaf(xf, vc.psx, -(vc.vw_half + cam.x));
+        const float uy0 = __builtin_fmaf(yf, vc.psy, -(vc.vh_half + cam.y));
 
-    auto write_pixel = [&]() {
-        if(valid && part == 0u) {
-            if constexpr(EXACT && ONE) {
-                if(culled) {
-                    const float4 t = row_miss[y];
-                    sum = f3{t.x, t.y, t.z};
+        // One sphere: the discriminant h*h - dd*c of the unnormalised ray (u, v, dz) is a quadratic in
+        // (u, v) with the coefficients of camera_consts; along a row of cells v is fixed and
+        //   disc(u) = u * (q_uu * u + B) + C,   B = q_uv v + q_u,   C = v (q_vv v + q_v) + q_0:
+        // two fmas per sample.  Every term of the expansion is at most a few times
+        // M = h*h + dd*(oc.oc + r*r), so this evaluation is, like the direct one, within a few dozen
+        // unit roundoffs of M of the real value.  The exact build screens with it: its constant term
+        // takes the margin times an upper bound of M over the pixel (all terms taken positive at the
+        // corner of the pixel farthest from the axes).
+        float screen_margin = 0.0f;
+        if constexpr(ONE && EXACT) {
+            const float ua = fmaxf(fabsf(ux0), fabsf(ux0 + vc.psx));
+            const float va = fmaxf(fabsf(uy0), fabsf(uy0 + vc.psy));
+            const float hmax = __builtin_fmaf(ua, fabsf(cc.oc[0]), __builtin_fmaf(va, fabsf(cc.oc[1]), fabsf(dz * cc.oc[2])));
+            const float ddmax = __builtin_fmaf(ua, ua, __builtin_fmaf(va, va, dz2));
+            screen_margin = (kScreenMargin * 1.001f) * __builtin_fmaf(ddmax, cc.magnitude, hmax * hmax);
+        }
+
+        // a row of cells inside the sample range [s, s_end): which cells, and where they sit
+        struct cell_row {
+            uint32_t count;         // cells of the row inside the range
+            uint32_t first_cell;    // index of the first of them
+            uint32_t cells;         // cells in the whole row
+            float first;            // first_cell as a float
+            float inv_cells;        // 1 / cells (exact for a full row)
+            float jy;               // vertical position of the row's samples in the pixel
+        };
+        // (the integers are the same in every lane; saying so keeps the sample loops' counters and
+        // branches in the scalar unit wherever the loops sit)
+        auto row_at = [&](uint32_t s, uint32_t s_end) {
+            cell_row cr;
+            if(!jitter) {           // every sample at the pixel centre: one "row" for the whole range
+                cr.count = __builtin_amdgcn_readfirstlane(s_end - s);
+                cr.first_cell = 0u;
+                cr.cells = 1u;
+                cr.first = 0.0f;
+                cr.inv_cells = 0.0f;
+                cr.jy = 0.5f;
+                return cr;
+            }
+            const uint32_t r = __builtin_amdgcn_readfirstlane(s >> vc.row_bits);
+            const uint32_t n_r = __builtin_amdgcn_readfirstlane(cells_in_row(vc, r));
+            cr.count = __builtin_amdgcn_readfirstlane(min(s_end, (r << vc.row_bits) + n_r) - s);
+            cr.first_cell = __builtin_amdgcn_readfirstlane(s & (row_cells - 1u));
+            cr.cells = n_r;
+            cr.first = static_cast<float>(cr.first_cell);
+            // (a power of two in all rows but a ragged last one: its reciprocal comes from the exponent,
+            // in the scalar unit, instead of a division)
+            cr.inv_cells = (n_r & (n_r - 1u)) == 0u ? __uint_as_float((127u - static_cast<uint32_t>(__builtin_ctz(n_r))) << 23)
+                                                    : __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(1.0f / static_cast<float>(n_r))));
+            cr.jy = (static_cast<float>(r << vc.row_bits) + off.ry * static_cast<float>(n_r)) * vc.inv_spp;
+            return cr;
+        };
+
+        f3 sum = {0.0f, 0.0f, 0.0f};
+
+        auto write_pixel = [&]() {
+            if(valid && part == 0u) {
+                if constexpr(EXACT && ONE) {
+                    if(culled) sum = all_miss_total(y);
+                }
+                store_pixel(x, row, sum);
+            }
+        };
+
+        if constexpr(EXACT) {
+            for(uint32_t first = 0; first < nblocks; first += split) {      // a round: `split` consecutive blocks
+                const uint32_t blk = first + part;
+                f3 block = {0.0f, 0.0f, 0.0f};
+                if(blk < nblocks && work) {
+                    const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
+                    const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
+                    for(uint32_t s = s0; s < s1;) {
+                        const cell_row cr = row_at(s, s1);
+                        s += cr.count;
+                        // the row's part of the sample's ray exactly as the reference builds it
+                        // (src/software_raytracer.cpp:218-221), and of the folded screening ray
+                        const float py = yf + cr.jy;
+                        const float draw_y = (py * vc.psy - vc.vh_half) - cam.y;
+                        const float v = __builtin_fmaf(cr.jy, vc.psy, uy0);
+                        const float du = vc.psx * cr.inv_cells;
+                        const float u_first = __builtin_fmaf(jitter ? off.rx * cr.inv_cells : 0.5f, vc.psx, ux0);
+                        float qb = 0.0f, qc = 0.0f;
+                        if constexpr(ONE && FOLD) {
+                            qb = __builtin_fmaf(cc.q_uv, v, cc.q_u);
+                            qc = __builtin_fmaf(v, __builtin_fmaf(cc.q_vv, v, cc.q_v), cc.q_0) + screen_margin;
+                        }
+                        float cell = cr.first;
+                        for(uint32_t k = 0; k < cr.count; k++, cell += 1.0f) {
+                            // Conservative miss test on the unnormalised ray in fused arithmetic.  With
+                            // h = draw.oc and dd = draw.draw the reference's discriminant has the sign of
+                            // h*h - dd*c.  Both evaluations are within about a dozen unit roundoffs of
+                            // h*h + dd*(oc.oc + r*r), so a value below -kScreenMargin of that magnitude is
+                            // negative in the exact evaluation as well, and the sample takes the row
+                            // background whatever its direction is.  Everything else runs the exact
+                            // arithmetic below.  Where the camera is not close to the viewport plane (host
+                            // check, kFlagFoldScreen) the screening ray comes from fmas instead of the
+                            // reference's operations: it differs from the exact ray by a few ulps of the
+                            // viewport extent, which moves the screening value by under 6e-6 of the
+                            // magnitude -- inside the margin with room to spare.
+                            auto exact_draw = [&]() {
+                                const float jx = jitter ? (cell + off.rx) * cr.inv_cells : 0.5f;
+                                const float px = xf + jx;
+                                return f3{(px * vc.psx - vc.vw_half) - cam.x, draw_y, dz};
+                            };
+                            f3 draw = {0.0f, 0.0f, dz};
+                            bool maybe = false;
+                            if constexpr(ONE && FOLD) {
+                                const float u = __builtin_fmaf(cell, du, u_first);
+                                maybe = __builtin_fmaf(u, __builtin_fmaf(cc.q_uu, u, qb), qc) >= 0.0f;
+                            } else {
+                                float rx, ry;
+                                if constexpr(FOLD) {
+                                    rx = __builtin_fmaf(cell, du, u_first);
+                                    ry = v;
+                                } else {
+                                    draw = exact_draw();
+                                    rx = draw.x;
+                                    ry = draw.y;
+                                }
+                                const float dd = __builtin_fmaf(ry, ry, __builtin_fmaf(rx, rx, dz2));
+                                for(uint32_t i = 0; i < n_spheres; i++) {
+                                    const float4 kk = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
+                                    const float mag = ONE ? cc.magnitude : s_ctr[i].w;
+                                    const float h = __builtin_fmaf(ry, kk.y, __builtin_fmaf(rx, kk.x, dz * kk.z));
+                                    const float q = h * h;
+                                    const float screen = __builtin_fmaf(kScreenMargin, __builtin_fmaf(dd, mag, q), __builtin_fmaf(-dd, kk.w, q));
+                                    maybe = maybe || (screen >= 0.0f);
+                                }
+                            }
+                            if constexpr(FOLD) {
+                                if(maybe) draw = exact_draw();
+                            }
+
+                            f3 L = bg;
+                            if(maybe) {
+                                const f3 d = normalize3<true>(draw);
+                                const float a = dot3<true>(d, d);
+                                const float a4 = 4.0f * a;
+                                const float a2 = 2.0f * a;
+                                float closest = 3.402823466e+38f;
+                                int hit = -1;
+                                for(uint32_t i = 0; i < n_spheres; i++) {
+                                    const float4 kk = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
+                                    const float b = -2.0f * dot3<true>(d, f3{kk.x, kk.y, kk.z});
+                                    const float disc = b * b - a4 * kk.w;
+                                    if(disc >= 0.0f) {
+                                        // FAST_AFTER_DISC: up to here the sample is the reference's, bit for
+                                        // bit (ray, normalisation, discriminant -- where its rounding is
+                                        // amplified); from here on nothing amplifies, and the hardware's
+                                        // approximate square root and reciprocals are within 1e-6 of it
+                                        const float sq = FAST_AFTER_DISC ? __builtin_amdgcn_sqrtf(disc) : rt_sqrt<true>(disc);
+                                        const float inv_a2 = FAST_AFTER_DISC ? __builtin_amdgcn_rcpf(a2) : 0.0f;
+                                        float t = FAST_AFTER_DISC ? (-b - sq) * inv_a2 : (-b - sq) / a2;
+                                        bool ok = (t > kTMin) && (t < closest);
+                                        if(!ok) {
+                                            // rare (camera inside a sphere): keep it a branch -- computed
+                                            // unconditionally, the second IEEE division costs every hit 13 issue slots
+                                            asm volatile("");
+                                            t = FAST_AFTER_DISC ? (-b + sq) * inv_a2 : (-b + sq) / a2;
+                                            ok = (t > kTMin) && (t < closest);
+                                        }
+                                        if(ok) {
+                                            closest = t;
+                                            hit = static_cast<int>(i);
+                                        }
+                                    }
+                                }
+                                if(hit >= 0) {
+                                    const f3 ctr = ONE ? f3{cc.center[0], cc.center[1], cc.center[2]}
+                                                       : f3{s_ctr[hit].x, s_ctr[hit].y, s_ctr[hit].z};
+                                    if constexpr(FAST_AFTER_DISC) {
+                                        const f3 w = {__builtin_fmaf(d.x, closest, cam.x - ctr.x), __builtin_fmaf(d.y, closest, cam.y - ctr.y),
+                                                      __builtin_fmaf(d.z, closest, cam.z - ctr.z)};
+                                        const float half_inv = 0.5f * __builtin_amdgcn_rsqf(dot3<false>(w, w));
+                                        L = f3{__builtin_fmaf(w.x, half_inv, 0.5f), __builtin_fmaf(w.y, half_inv, 0.5f), __builtin_fmaf(w.z, half_inv, 0.5f)};
+                                    } else {
+                                        const f3 pt = {d.x * closest + cam.x, d.y * closest + cam.y, d.z * closest + cam.z};
+                                        const f3 n = normalize3<true>(f3{pt.x - ctr.x, pt.y - ctr.y, pt.z - ctr.z});
+                                        L = f3{remap_unit(n.x), remap_unit(n.y), remap_unit(n.z)};      // throughput is 1
+                                    }
+                                }
+                            }
+                            block.x += L.x;
+                            block.y += L.y;
+                            block.z += L.z;
+                        }
+                    }
+                }
+                if(split == 1u) {
+                    sum.x += block.x;
+                    sum.y += block.y;
+                    sum.z += block.z;
+                } else {
+                    // hand the block sum to the strip's other waves; every wave adds the round's sums in
+                    // block order to its own copy of the total.  Two buffers alternate, so the barrier
+                    // of the next round also orders this round's reads before the buffer's next writes.
+                    const uint32_t buf = (first >> split_log2) & 1u;
+                    s_part[buf][wave][0][lane] = block.x;
+                    s_part[buf][wave][1][lane] = block.y;
+                    s_part[buf][wave][2][lane] = block.z;
+                    __syncthreads();
+                    const uint32_t live = min(split, nblocks - first);
+                    const uint32_t w0 = wave - part;       // the strip's first wave
+                    for(uint32_t p = 0; p < live; p++) {
+                        sum.x += s_part[buf][w0 + p][0][lane];
+                        sum.y += s_part[buf][w0 + p][1][lane];
+                        sum.z += s_part[buf][w0 + p][2][lane];
+                    }
                 }
             }
-            const float n = static_cast<float>(vc.spp);
-            // the mean is a true division in both builds (once per pixel): an approximate reciprocal
-            // would turn a row of exact 1.0 samples into 0.99999994 and the truncating pack into 254
-            const float r = clamp01(sum.x / n);
-            const float g = clamp01(sum.y / n);
-            const float b = clamp01(sum.z / n);
-            const size_t idx = static_cast<size_t>(row) * vc.width + x;
-            argb[idx] = pack_argb32(r, g, b);
-            if(rgba) rgba[idx] = make_float4(r, g, b, 1.0f);
-        }
-    };
-
-    if constexpr(ONE) {
-        // a workgroup none of whose pixels is in the sample loop (most of the frame around the sphere)
-        if(group_idle) {
-            if constexpr(!EXACT) {
-                const float misses = static_cast<float>(vc.spp);
-                sum = f3{misses * bg.x, misses * bg.y, misses * bg.z};
+        } else {
+            // fast build: the ray stays unnormalised (the hit test is scale invariant, t runs
+            // along `draw`); only hits add to the sum, misses are counted and added as
+            // (misses * background); the order of additions is free
+            uint32_t hits = 0;
+            f3 hit = {0.0f, 0.0f, 0.0f};        // the hit loop's sums, before the factor c * shade_scale
+            // the hit loop's two per-sample constants, in vector registers: an instruction with a
+            // scalar-register operand issues at half the rate of one without (measured, tools/valu_peak.hip)
+            float q_uu_v = 0.0f, oc_x_v = 0.0f, c4_v = 0.0f;
+            if constexpr(ONE) {
+                asm volatile("v_mov_b32 %0, %1" : "=v"(q_uu_v) : "s"(cc.q_uu));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(oc_x_v) : "s"(cc.oc[0]));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(c4_v) : "s"(0.25f * cc.c));
             }
-            write_pixel();
-            return;
-        }
-    }
-
-    if constexpr(EXACT) {
-        for(uint32_t first = 0; first < nblocks; first += split) {      // a round: `split` consecutive blocks
-            const uint32_t blk = first + part;
-            f3 block = {0.0f, 0.0f, 0.0f};
-            if(blk < nblocks && work) {
+            // The Newton hit loop's view of the pixel: T = t / 2 = c / (2 (h + sqrt(disc))) and
+            // rho = 1 / sqrt(disc) at the centre of the pixel with their gradients over the viewport.
+            // rho is used as that first-order expansion throughout the pixel; T's expansion only
+            // starts the rows (d disc / du = 2 (h oc.x - c u), likewise in v).
+            struct newton_pixel {
+                float u_c, v_c, rho_c, rho_u, rho_v, T_c, T_u, T_v;
+            };
+            newton_pixel np = {};
+            if constexpr(ONE) {
+                if(newton) {
+                    np.u_c = __builtin_fmaf(0.5f, vc.psx, ux0);
+                    np.v_c = __builtin_fmaf(0.5f, vc.psy, uy0);
+                    const float h_c = __builtin_fmaf(np.u_c, cc.oc[0], __builtin_fmaf(np.v_c, cc.oc[1], dz * cc.oc[2]));
+                    const float dd_c = __builtin_fmaf(np.u_c, np.u_c, __builtin_fmaf(np.v_c, np.v_c, dz2));
+                    const float disc_c = __builtin_fmaf(-dd_c, cc.c, h_c * h_c);
+                    np.rho_c = __builtin_amdgcn_rsqf(disc_c);
+                    const float inv_w = __builtin_amdgcn_rcpf(__builtin_fmaf(disc_c, np.rho_c, h_c));
+                    np.T_c = (0.5f * cc.c) * inv_w;
+                    const float half_disc_u = __builtin_fmaf(h_c, cc.oc[0], -(cc.c * np.u_c));
+                    const float half_disc_v = __builtin_fmaf(h_c, cc.oc[1], -(cc.c * np.v_c));
+                    const float rho3 = -(np.rho_c * np.rho_c) * np.rho_c;
+                    np.rho_u = rho3 * half_disc_u;
+                    np.rho_v = rho3 * half_disc_v;
+                    const float t_w = -np.T_c * inv_w;
+                    np.T_u = t_w * __builtin_fmaf(np.rho_c, half_disc_u, cc.oc[0]);
+                    np.T_v = t_w * __builtin_fmaf(np.rho_c, half_disc_v, cc.oc[1]);
+                }
+            }
+            for(uint32_t blk = part; blk < nblocks; blk += split) {
                 const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
                 const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
+                if constexpr(ONE) {
+                    if(newton) {
+                        // The hit loop without a square root or a reciprocal (see kNewtonTolerance):
+                        // T = t / 2 of the previous cell takes one Newton step on
+                        //   f / 4 = dd T*T - h T + c / 4,   (f / 4)' = 2 dd T - h = -sqrt(disc) at the near root,
+                        // with rho ~ 1 / sqrt(disc) from its first-order expansion about the pixel's centre
+                        // (one add a cell).  Nine full-rate vector instructions a sample; two rows
+                        // of equal length are walked side by side (they share u and u*u, and two
+                        // independent chains keep the vector unit fed: measured 21 clocks a sample
+                        // against 24 for one row at a time).
+                        struct newton_row {
+                            float v, h_row, dd_row, rho, T;
+                        };
+                        // where a row starts: 1 / sqrt(disc) one cell before its first cell, and T at the
+                        // first cell (the first step refines it), both from their expansions about the
+                        // pixel's centre (newton_pixel, below)
+                        auto start_row = [&](const cell_row &cr, float u_first, float du) {
+                            newton_row nr;
+                            nr.v = __builtin_fmaf(cr.jy, vc.psy, uy0);
+                            nr.h_row = __builtin_fmaf(nr.v, cc.oc[1], dz * cc.oc[2]);
+                            nr.dd_row = __builtin_fmaf(nr.v, nr.v, dz2);
+                            const float off_u = u_first - np.u_c, off_v = nr.v - np.v_c;
+                            nr.rho = __builtin_fmaf(np.rho_u, off_u - du, __builtin_fmaf(np.rho_v, off_v, np.rho_c));
+                            nr.T = __builtin_fmaf(np.T_u, off_u, __builtin_fmaf(np.T_v, off_v, np.T_c));
+                            return nr;
+                        };
+                        for(uint32_t s = s0; s < s1;) {
+                            const cell_row cr = row_at(s, s1);
+                            s += cr.count;
+                            const float du = jitter ? vc.psx * cr.inv_cells : 0.0f;
+                            const float u_first = __builtin_fmaf(jitter ? (cr.first + off.rx) * cr.inv_cells : 0.5f, vc.psx, ux0);
+                            float u = u_first - du;
+                            const float drho = np.rho_u * du;
+                            newton_row ra = start_row(cr, u_first, du);
+                            bool pair = false;
+                            cell_row cr2 = cr;
+                            if(s < s1) {
+                                cr2 = row_at(s, s1);
+                                pair = cr2.count == cr.count && cr2.first_cell == cr.first_cell && cr2.cells == cr.cells;
+                            }
+                            if(pair) {
+                                s += cr2.count;
+                                newton_row rb = start_row(cr2, u_first, du);
+                                float scale_a = 0.0f, scale_b = 0.0f;
+#pragma unroll 2
+                                for(uint32_t k = 0; k < cr.count; k++) {
+                                    u += du;
+                                    ra.rho += drho;
+                                    rb.rho += drho;
+                                    const float uu = u * u;
+                                    const float dd_a = uu + ra.dd_row, dd_b = uu + rb.dd_row;
+                                    const float h_a = __builtin_fmaf(u, oc_x_v, ra.h_row), h_b = __builtin_fmaf(u, oc_x_v, rb.h_row);
+                                    const float f4_a = __builtin_fmaf(ra.T, __builtin_fmaf(dd_a, ra.T, -h_a), c4_v);
+                                    const float f4_b = __builtin_fmaf(rb.T, __builtin_fmaf(dd_b, rb.T, -h_b), c4_v);
+                                    ra.T = __builtin_fmaf(f4_a, ra.rho, ra.T);
+                                    rb.T = __builtin_fmaf(f4_b, rb.rho, rb.T);
+                                    scale_a += ra.T;
+                                    scale_b += rb.T;
+                                    hit.x = __builtin_fmaf(u, ra.T + rb.T, hit.x);
+                                }
+                                hit.y = __builtin_fmaf(ra.v, scale_a, __builtin_fmaf(rb.v, scale_b, hit.y));
+                                hit.z += scale_a + scale_b;
+                                hits += 2u * cr.count;
+                            } else {
+                                float row_scale = 0.0f;
+#pragma unroll 4
+                                for(uint32_t k = 0; k < cr.count; k++) {
+                                    u += du;
+                                    ra.rho += drho;
+                                    const float dd = __builtin_fmaf(u, u, ra.dd_row);
+                                    const float h = __builtin_fmaf(u, oc_x_v, ra.h_row);
+                                    const float f4 = __builtin_fmaf(ra.T, __builtin_fmaf(dd, ra.T, -h), c4_v);
+                                    ra.T = __builtin_fmaf(f4, ra.rho, ra.T);
+                                    hit.x = __builtin_fmaf(u, ra.T, hit.x);
+                                    row_scale += ra.T;
+                                }
+                                hit.y = __builtin_fmaf(ra.v, row_scale, hit.y);
+                                hit.z += row_scale;
+                                hits += cr.count;
+                            }
+                        }
+                    }
+                    if(sure_hit) {
+                        // The hit loop: every sample of the pixel hits at the near root (see the
+                        // general loop below for the algebra).  Nine vector instructions a sample,
+                        // no test and no branch; the factor c * shade_scale is applied to the sums.
+                        for(uint32_t s = s0; s < s1;) {
+                            const cell_row cr = row_at(s, s1);
+                            s += cr.count;
+                            const float v = __builtin_fmaf(cr.jy, vc.psy, uy0);
+                            const float du = jitter ? vc.psx * cr.inv_cells : 0.0f;
+                            float u = __builtin_fmaf(jitter ? (cr.first + off.rx) * cr.inv_cells : 0.5f, vc.psx, ux0) - du;
+                            const float qb = __builtin_fmaf(cc.q_uv, v, cc.q_u);
+                            const float qc = __builtin_fmaf(v, __builtin_fmaf(cc.q_vv, v, cc.q_v), cc.q_0);
+                            const float h_row = __builtin_fmaf(v, cc.oc[1], dz * cc.oc[2]);
+                            float row_scale = 0.0f;
+#pragma unroll 4
+                            for(uint32_t k = 0; k < cr.count; k++) {
+                                u += du;
+                                const float disc = __builtin_fmaf(u, __builtin_fmaf(q_uu_v, u, qb), qc);
+                                const float h = __builtin_fmaf(u, oc_x_v, h_row);
+                                // the near root over dd, (h - sqrt(disc)) / dd, is c / (h + sqrt(disc)):
+                                // (h - s)(h + s) = h*h - disc = dd * c.  No cancellation, and dd is not needed.
+                                const float sc = __builtin_amdgcn_rcpf(h + __builtin_amdgcn_sqrtf(disc));
+                                hit.x = __builtin_fmaf(u, sc, hit.x);
+                                row_scale += sc;
+                            }
+                            hit.y = __builtin_fmaf(v, row_scale, hit.y);
+                            hit.z += row_scale;
+                            hits += cr.count;
+                        }
+                    }
+                }
+                if(!work || sure_hit || newton) continue;
                 for(uint32_t s = s0; s < s1;) {
                     const cell_row cr = row_at(s, s1);
                     s += cr.count;
-                    // the row's part of the sample's ray exactly as the reference builds it
-                    // (src/software_raytracer.cpp:218-221), and of the folded screening ray
-                    const float py = yf + cr.jy;
-                    const float draw_y = (py * vc.psy - vc.vh_half) - cam.y;
                     const float v = __builtin_fmaf(cr.jy, vc.psy, uy0);
-                    const float du = vc.psx * cr.inv_cells;
-                    const float u_first = __builtin_fmaf(jitter ? off.rx * cr.inv_cells : 0.5f, vc.psx, ux0);
-                    float qb = 0.0f, qc = 0.0f;
-                    if constexpr(ONE && FOLD) {
-                        qb = __builtin_fmaf(cc.q_uv, v, cc.q_u);
-                        qc = __builtin_fmaf(v, __builtin_fmaf(cc.q_vv, v, cc.q_v), cc.q_0) + screen_margin;
-                    }
-                    float cell = cr.first;
-                    for(uint32_t k = 0; k < cr.count; k++, cell += 1.0f) {
-                        // Conservative miss test on the unnormalised ray in fused arithmetic.  With
-                        // h = draw.oc and dd = draw.draw the reference's discriminant has the sign of
-                        // h*h - dd*c.  Both evaluations are within about a dozen unit roundoffs of
-                        // h*h + dd*(oc.oc + r*r), so a value below -kScreenMargin of that magnitude is
-                        // negative in the exact evaluation as well, and the sample takes the row
-                        // background whatever its direction is.  Everything else runs the exact
-                        // arithmetic below.  Where the camera is not close to the viewport plane (host
-                        // check, kFlagFoldScreen) the screening ray comes from fmas instead of the
-                        // reference's operations: it differs from the exact ray by a few ulps of the
-                        // viewport extent, which moves the screening value by under 6e-6 of the
-                        // magnitude -- inside the margin with room to spare.
-                        auto exact_draw = [&]() {
-                            const float jx = jitter ? (cell + off.rx) * cr.inv_cells : 0.5f;
-                            const float px = xf + jx;
-                            return f3{(px * vc.psx - vc.vw_half) - cam.x, draw_y, dz};
-                        };
-                        f3 draw = {0.0f, 0.0f, dz};
-                        bool maybe = false;
-                        if constexpr(ONE && FOLD) {
-                            const float u = __builtin_fmaf(cell, du, u_first);
-                            maybe = __builtin_fmaf(u, __builtin_fmaf(cc.q_uu, u, qb), qc) >= 0.0f;
-                        } else {
-                            float rx, ry;
-                            if constexpr(FOLD) {
-                                rx = __builtin_fmaf(cell, du, u_first);
-                                ry = v;
-                            } else {
-                                draw = exact_draw();
-                                rx = draw.x;
-                                ry = draw.y;
-                            }
-                            const float dd = __builtin_fmaf(ry, ry, __builtin_fmaf(rx, rx, dz2));
-                            for(uint32_t i = 0; i < n_spheres; i++) {
-                                const float4 kk = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
-                                const float mag = ONE ? cc.magnitude : s_ctr[i].w;
-                                const float h = __builtin_fmaf(ry, kk.y, __builtin_fmaf(rx, kk.x, dz * kk.z));
-                                const float q = h * h;
-                                const float screen = __builtin_fmaf(kScreenMargin, __builtin_fmaf(dd, mag, q), __builtin_fmaf(-dd, kk.w, q));
-                                maybe = maybe || (screen >= 0.0f);
+                    const float du = jitter ? vc.psx * cr.inv_cells : 0.0f;
+                    // u of the cell before the row's first: the loop steps before it tests
+                    float u = __builtin_fmaf(jitter ? (cr.first + off.rx) * cr.inv_cells : 0.5f, vc.psx, ux0) - du;
+                    if constexpr(ONE) {
+                        const float qb = __builtin_fmaf(cc.q_uv, v, cc.q_u);
+                        const float qc = __builtin_fmaf(v, __builtin_fmaf(cc.q_vv, v, cc.q_v), cc.q_0);
+                        const float h_row = __builtin_fmaf(v, cc.oc[1], dz * cc.oc[2]);       // h = u oc.x + h_row
+                        const float dd_row = __builtin_fmaf(v, v, dz2);                      // dd = u u + dd_row
+                        float row_scale = 0.0f;
+                        // a missing sample is four vector instructions: step, two fmas, compare
+#pragma unroll 4
+                        for(uint32_t k = 0; k < cr.count; k++) {
+                            u += du;
+                            const float disc = __builtin_fmaf(u, __builtin_fmaf(cc.q_uu, u, qb), qc);
+                            if(disc >= 0.0f) {
+                                const float dd = __builtin_fmaf(u, u, dd_row);
+                                const float h = __builtin_fmaf(u, cc.oc[0], h_row);
+                                // The hit is at draw * t, t = root / dd, root = h -+ sqrt(disc); it lies
+                                // beyond t_min when root > 0 and root*root > t_min^2 * dd.  With the
+                                // camera outside the sphere by more than t_min (near_root_only) the two
+                                // roots have the sign of h and the near one always passes.
+                                // A point of the sphere is a radius away from the centre, so the
+                                // normal is (draw*t - oc) / r without a normalisation, and its colour
+                                // 0.5*n + 0.5 = draw * (0.5 t / r) + (0.5 - 0.5 oc / r).  The sum over
+                                // the pixel's hits needs only sum(u*s), sum(v*s), sum(s) with
+                                // s = 0.5 t / r (v and dz leave the sums of a row and of the pixel); the
+                                // constant parts are added once, below.
+                                const float sq = __builtin_amdgcn_sqrtf(disc);
+                                float root = h - sq;
+                                bool ok;
+                                if(cc.near_root_only != 0u) {
+                                    ok = h > 0.0f;
+                                } else {
+                                    const float far_enough = (kTMin * kTMin) * dd;
+                                    if(!(root > 0.0f && root * root > far_enough)) root = h + sq;
+                                    ok = root > 0.0f && root * root > far_enough;
+                                }
+                                if(ok) {
+                                    const float sc = (root * cc.shade_scale) * __builtin_amdgcn_rcpf(dd);
+                                    sum.x = __builtin_fmaf(u, sc, sum.x);
+                                    row_scale += sc;
+                                    hits++;
+                                }
                             }
                         }
-                        if constexpr(FOLD) {
-                            if(maybe) draw = exact_draw();
-                        }
-
-                        f3 L = bg;
-                        if(maybe) {
-                            const f3 d = normalize3<true>(draw);
-                            const float a = dot3<true>(d, d);
-                            const float a4 = 4.0f * a;
-                            const float a2 = 2.0f * a;
+                        sum.y = __builtin_fmaf(v, row_scale, sum.y);
+                        sum.z += row_scale;
+                    } else {
+                        const float dd_row = __builtin_fmaf(v, v, dz2);
+                        for(uint32_t k = 0; k < cr.count; k++) {
+                            u += du;
+                            const float dd = __builtin_fmaf(u, u, dd_row);
                             float closest = 3.402823466e+38f;
                             int hit = -1;
                             for(uint32_t i = 0; i < n_spheres; i++) {
-                                const float4 kk = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
-                                const float b = -2.0f * dot3<true>(d, f3{kk.x, kk.y, kk.z});
-                                const float disc = b * b - a4 * kk.w;
+                                const float4 kk = s_occ[i];
+                                const float h = __builtin_fmaf(v, kk.y, __builtin_fmaf(u, kk.x, dz * kk.z));
+                                const float disc = __builtin_fmaf(-dd, kk.w, h * h);
                                 if(disc >= 0.0f) {
-                                    // FAST_AFTER_DISC: up to here the sample is the reference's, bit for
-                                    // bit (ray, normalisation, discriminant -- where its rounding is
-                                    // amplified); from here on nothing amplifies, and the hardware's
-                                    // approximate square root and reciprocals are within 1e-6 of it
-                                    const float sq = FAST_AFTER_DISC ? __builtin_amdgcn_sqrtf(disc) : rt_sqrt<true>(disc);
-                                    const float inv_a2 = FAST_AFTER_DISC ? __builtin_amdgcn_rcpf(a2) : 0.0f;
-                                    float t = FAST_AFTER_DISC ? (-b - sq) * inv_a2 : (-b - sq) / a2;
-                                    bool ok = (t > kTMin) && (t < closest);
+                                    const float sq = __builtin_amdgcn_sqrtf(disc);
+                                    const float inv = __builtin_amdgcn_rcpf(dd);
+                                    const float tmin = kTMin * __builtin_amdgcn_rsqf(dd);       // t_min in units of |draw|
+                                    float t = (h - sq) * inv;
+                                    bool ok = (t > tmin) && (t < closest);
                                     if(!ok) {
-                                        // rare (camera inside a sphere): keep it a branch -- computed
-                                        // unconditionally, the second IEEE division costs every hit 13 issue slots
-                                        asm volatile("");
-                                        t = FAST_AFTER_DISC ? (-b + sq) * inv_a2 : (-b + sq) / a2;
-                                        ok = (t > kTMin) && (t < closest);
+                                        t = (h + sq) * inv;
+                                        ok = (t > tmin) && (t < closest);
                                     }
                                     if(ok) {
                                         closest = t;
@@ -1746,224 +2138,57 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                                 }
                             }
                             if(hit >= 0) {
-                                const f3 ctr = ONE ? f3{cc.center[0], cc.center[1], cc.center[2]}
-                                                   : f3{s_ctr[hit].x, s_ctr[hit].y, s_ctr[hit].z};
-                                if constexpr(FAST_AFTER_DISC) {
-                                    const f3 w = {__builtin_fmaf(d.x, closest, cam.x - ctr.x), __builtin_fmaf(d.y, closest, cam.y - ctr.y),
-                                                  __builtin_fmaf(d.z, closest, cam.z - ctr.z)};
-                                    const float half_inv = 0.5f * __builtin_amdgcn_rsqf(dot3<false>(w, w));
-                                    L = f3{__builtin_fmaf(w.x, half_inv, 0.5f), __builtin_fmaf(w.y, half_inv, 0.5f), __builtin_fmaf(w.z, half_inv, 0.5f)};
-                                } else {
-                                    const f3 pt = {d.x * closest + cam.x, d.y * closest + cam.y, d.z * closest + cam.z};
-                                    const f3 n = normalize3<true>(f3{pt.x - ctr.x, pt.y - ctr.y, pt.z - ctr.z});
-                                    L = f3{remap_unit(n.x), remap_unit(n.y), remap_unit(n.z)};      // throughput is 1
-                                }
-                            }
-                        }
-                        block.x += L.x;
-                        block.y += L.y;
-                        block.z += L.z;
-                    }
-                }
-            }
-            if(split == 1u) {
-                sum.x += block.x;
-                sum.y += block.y;
-                sum.z += block.z;
-            } else {
-                // hand the block sum to the strip's other waves; every wave adds the round's sums in
-                // block order to its own copy of the total.  Two buffers alternate, so the barrier
-                // of the next round also orders this round's reads before the buffer's next writes.
-                const uint32_t buf = (first >> split_log2) & 1u;
-                s_part[buf][wave][0][lane] = block.x;
-                s_part[buf][wave][1][lane] = block.y;
-                s_part[buf][wave][2][lane] = block.z;
-                __syncthreads();
-                const uint32_t live = min(split, nblocks - first);
-                const uint32_t w0 = strip << split_log2;
-                for(uint32_t p = 0; p < live; p++) {
-                    sum.x += s_part[buf][w0 + p][0][lane];
-                    sum.y += s_part[buf][w0 + p][1][lane];
-                    sum.z += s_part[buf][w0 + p][2][lane];
-                }
-            }
-        }
-    } else {
-        // fast build: the ray stays unnormalised (the hit test is scale invariant, t runs
-        // along `draw`); only hits add to the sum, misses are counted and added as
-        // (misses * background); the order of additions is free
-        uint32_t hits = 0;
-        f3 hit = {0.0f, 0.0f, 0.0f};        // the hit loop's sums, before the factor c * shade_scale
-        // the hit loop's two per-sample constants, in vector registers: an instruction with a
-        // scalar-register operand issues at half the rate of one without (measured, tools/valu_peak.hip)
-        float q_uu_v = 0.0f, oc_x_v = 0.0f;
-        if constexpr(ONE) {
-            asm volatile("v_mov_b32 %0, %1" : "=v"(q_uu_v) : "s"(cc.q_uu));
-            asm volatile("v_mov_b32 %0, %1" : "=v"(oc_x_v) : "s"(cc.oc[0]));
-        }
-        for(uint32_t blk = part; blk < nblocks; blk += split) {
-            const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
-            const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
-            if constexpr(ONE) {
-                if(sure_hit) {
-                    // The hit loop: every sample of the pixel hits at the near root (see the
-                    // general loop below for the algebra).  Nine vector instructions a sample,
-                    // no test and no branch; the factor c * shade_scale is applied to the sums.
-                    for(uint32_t s = s0; s < s1;) {
-                        const cell_row cr = row_at(s, s1);
-                        s += cr.count;
-                        const float v = __builtin_fmaf(cr.jy, vc.psy, uy0);
-                        const float du = jitter ? vc.psx * cr.inv_cells : 0.0f;
-                        float u = __builtin_fmaf(jitter ? (cr.first + off.rx) * cr.inv_cells : 0.5f, vc.psx, ux0) - du;
-                        const float qb = __builtin_fmaf(cc.q_uv, v, cc.q_u);
-                        const float qc = __builtin_fmaf(v, __builtin_fmaf(cc.q_vv, v, cc.q_v), cc.q_0);
-                        const float h_row = __builtin_fmaf(v, cc.oc[1], dz * cc.oc[2]);
-                        float row_scale = 0.0f;
-#pragma unroll 4
-                        for(uint32_t k = 0; k < cr.count; k++) {
-                            u += du;
-                            const float disc = __builtin_fmaf(u, __builtin_fmaf(q_uu_v, u, qb), qc);
-                            const float h = __builtin_fmaf(u, oc_x_v, h_row);
-                            // the near root over dd, (h - sqrt(disc)) / dd, is c / (h + sqrt(disc)):
-                            // (h - s)(h + s) = h*h - disc = dd * c.  No cancellation, and dd is not needed.
-                            const float sc = __builtin_amdgcn_rcpf(h + __builtin_amdgcn_sqrtf(disc));
-                            hit.x = __builtin_fmaf(u, sc, hit.x);
-                            row_scale += sc;
-                        }
-                        hit.y = __builtin_fmaf(v, row_scale, hit.y);
-                        hit.z += row_scale;
-                        hits += cr.count;
-                    }
-                }
-            }
-            if(!work || sure_hit) continue;
-            for(uint32_t s = s0; s < s1;) {
-                const cell_row cr = row_at(s, s1);
-                s += cr.count;
-                const float v = __builtin_fmaf(cr.jy, vc.psy, uy0);
-                const float du = jitter ? vc.psx * cr.inv_cells : 0.0f;
-                // u of the cell before the row's first: the loop steps before it tests
-                float u = __builtin_fmaf(jitter ? (cr.first + off.rx) * cr.inv_cells : 0.5f, vc.psx, ux0) - du;
-                if constexpr(ONE) {
-                    const float qb = __builtin_fmaf(cc.q_uv, v, cc.q_u);
-                    const float qc = __builtin_fmaf(v, __builtin_fmaf(cc.q_vv, v, cc.q_v), cc.q_0);
-                    const float h_row = __builtin_fmaf(v, cc.oc[1], dz * cc.oc[2]);       // h = u oc.x + h_row
-                    const float dd_row = __builtin_fmaf(v, v, dz2);                      // dd = u u + dd_row
-                    float row_scale = 0.0f;
-                    // a missing sample is four vector instructions: step, two fmas, compare
-#pragma unroll 4
-                    for(uint32_t k = 0; k < cr.count; k++) {
-                        u += du;
-                        const float disc = __builtin_fmaf(u, __builtin_fmaf(cc.q_uu, u, qb), qc);
-                        if(disc >= 0.0f) {
-                            const float dd = __builtin_fmaf(u, u, dd_row);
-                            const float h = __builtin_fmaf(u, cc.oc[0], h_row);
-                            // The hit is at draw * t, t = root / dd, root = h -+ sqrt(disc); it lies
-                            // beyond t_min when root > 0 and root*root > t_min^2 * dd.  With the
-                            // camera outside the sphere by more than t_min (near_root_only) the two
-                            // roots have the sign of h and the near one always passes.
-                            // A point of the sphere is a radius away from the centre, so the
-                            // normal is (draw*t - oc) / r without a normalisation, and its colour
-                            // 0.5*n + 0.5 = draw * (0.5 t / r) + (0.5 - 0.5 oc / r).  The sum over
-                            // the pixel's hits needs only sum(u*s), sum(v*s), sum(s) with
-                            // s = 0.5 t / r (v and dz leave the sums of a row and of the pixel); the
-                            // constant parts are added once, below.
-                            const float sq = __builtin_amdgcn_sqrtf(disc);
-                            float root = h - sq;
-                            bool ok;
-                            if(cc.near_root_only != 0u) {
-                                ok = h > 0.0f;
-                            } else {
-                                const float far_enough = (kTMin * kTMin) * dd;
-                                if(!(root > 0.0f && root * root > far_enough)) root = h + sq;
-                                ok = root > 0.0f && root * root > far_enough;
-                            }
-                            if(ok) {
-                                const float sc = (root * cc.shade_scale) * __builtin_amdgcn_rcpf(dd);
-                                sum.x = __builtin_fmaf(u, sc, sum.x);
-                                row_scale += sc;
+                                const f3 ctr = {s_ctr[hit].x, s_ctr[hit].y, s_ctr[hit].z};
+                                const f3 w = {__builtin_fmaf(u, closest, cam.x - ctr.x), __builtin_fmaf(v, closest, cam.y - ctr.y),
+                                              __builtin_fmaf(dz, closest, cam.z - ctr.z)};
+                                const float half_inv = 0.5f * __builtin_amdgcn_rsqf(dot3<false>(w, w));
+                                sum.x += __builtin_fmaf(w.x, half_inv, 0.5f);
+                                sum.y += __builtin_fmaf(w.y, half_inv, 0.5f);
+                                sum.z += __builtin_fmaf(w.z, half_inv, 0.5f);
                                 hits++;
                             }
                         }
                     }
-                    sum.y = __builtin_fmaf(v, row_scale, sum.y);
-                    sum.z += row_scale;
-                } else {
-                    const float dd_row = __builtin_fmaf(v, v, dz2);
-                    for(uint32_t k = 0; k < cr.count; k++) {
-                        u += du;
-                        const float dd = __builtin_fmaf(u, u, dd_row);
-                        float closest = 3.402823466e+38f;
-                        int hit = -1;
-                        for(uint32_t i = 0; i < n_spheres; i++) {
-                            const float4 kk = s_occ[i];
-                            const float h = __builtin_fmaf(v, kk.y, __builtin_fmaf(u, kk.x, dz * kk.z));
-                            const float disc = __builtin_fmaf(-dd, kk.w, h * h);
-                            if(disc >= 0.0f) {
-                                const float sq = __builtin_amdgcn_sqrtf(disc);
-                                const float inv = __builtin_amdgcn_rcpf(dd);
-                                const float tmin = kTMin * __builtin_amdgcn_rsqf(dd);       // t_min in units of |draw|
-                                float t = (h - sq) * inv;
-                                bool ok = (t > tmin) && (t < closest);
-                                if(!ok) {
-                                    t = (h + sq) * inv;
-                                    ok = (t > tmin) && (t < closest);
-                                }
-                                if(ok) {
-                                    closest = t;
-                                    hit = static_cast<int>(i);
-                                }
-                            }
-                        }
-                        if(hit >= 0) {
-                            const f3 ctr = {s_ctr[hit].x, s_ctr[hit].y, s_ctr[hit].z};
-                            const f3 w = {__builtin_fmaf(u, closest, cam.x - ctr.x), __builtin_fmaf(v, closest, cam.y - ctr.y),
-                                          __builtin_fmaf(dz, closest, cam.z - ctr.z)};
-                            const float half_inv = 0.5f * __builtin_amdgcn_rsqf(dot3<false>(w, w));
-                            sum.x += __builtin_fmaf(w.x, half_inv, 0.5f);
-                            sum.y += __builtin_fmaf(w.y, half_inv, 0.5f);
-                            sum.z += __builtin_fmaf(w.z, half_inv, 0.5f);
-                            hits++;
-                        }
+                }
+            }
+            if constexpr(ONE) {
+                const float scale = (newton ? 2.0f : cc.c) * cc.shade_scale;        // the Newton loop sums t / 2, the closed-form loop t / c
+                sum.x = __builtin_fmaf(hit.x, scale, sum.x);
+                sum.y = __builtin_fmaf(hit.y, scale, sum.y);
+                sum.z = __builtin_fmaf(hit.z, scale, sum.z);
+            }
+            if(split > 1u) {
+                s_part[0][wave][0][lane] = sum.x;
+                s_part[0][wave][1][lane] = sum.y;
+                s_part[0][wave][2][lane] = sum.z;
+                s_hits[wave][lane] = hits;
+                __syncthreads();
+                if(part == 0u) {
+                    for(uint32_t p = 1; p < split; p++) {
+                        sum.x += s_part[0][wave + p][0][lane];
+                        sum.y += s_part[0][wave + p][1][lane];
+                        sum.z += s_part[0][wave + p][2][lane];
+                        hits += s_hits[wave + p][lane];
                     }
                 }
             }
-        }
-        if constexpr(ONE) {
-            const float scale = cc.c * cc.shade_scale;
-            sum.x = __builtin_fmaf(hit.x, scale, sum.x);
-            sum.y = __builtin_fmaf(hit.y, scale, sum.y);
-            sum.z = __builtin_fmaf(hit.z, scale, sum.z);
-        }
-        if(split > 1u) {
-            s_part[0][wave][0][lane] = sum.x;
-            s_part[0][wave][1][lane] = sum.y;
-            s_part[0][wave][2][lane] = sum.z;
-            s_hits[wave][lane] = hits;
-            __syncthreads();
-            if(part == 0u) {
-                for(uint32_t p = 1; p < split; p++) {
-                    sum.x += s_part[0][wave + p][0][lane];
-                    sum.y += s_part[0][wave + p][1][lane];
-                    sum.z += s_part[0][wave + p][2][lane];
-                    hits += s_hits[wave + p][lane];
-                }
+            if constexpr(ONE) {
+                // constant parts of the hits' colours (see the sample loop)
+                const float hf = static_cast<float>(hits);
+                sum.x = __builtin_fmaf(hf, cc.shade_offset[0], sum.x);
+                sum.y = __builtin_fmaf(hf, cc.shade_offset[1], sum.y);
+                sum.z = __builtin_fmaf(hf, cc.shade_offset[2], dz * sum.z);
             }
+            const float misses = static_cast<float>(vc.spp - hits);
+            sum.x = __builtin_fmaf(misses, bg.x, sum.x);
+            sum.y = __builtin_fmaf(misses, bg.y, sum.y);
+            sum.z = __builtin_fmaf(misses, bg.z, sum.z);
         }
-        if constexpr(ONE) {
-            // constant parts of the hits' colours (see the sample loop)
-            const float hf = static_cast<float>(hits);
-            sum.x = __builtin_fmaf(hf, cc.shade_offset[0], sum.x);
-            sum.y = __builtin_fmaf(hf, cc.shade_offset[1], sum.y);
-            sum.z = __builtin_fmaf(hf, cc.shade_offset[2], dz * sum.z);
-        }
-        const float misses = static_cast<float>(vc.spp - hits);
-        sum.x = __builtin_fmaf(misses, bg.x, sum.x);
-        sum.y = __builtin_fmaf(misses, bg.y, sum.y);
-        sum.z = __builtin_fmaf(misses, bg.z, sum.z);
-    }
 
-    write_pixel();
+        write_pixel();
+        // the next round's waves reuse the hand-over buffers
+        if(rounds > 1u && split > 1u) __syncthreads();
+    }
 
     // (Ray and lane-slot counts of this pass follow from the image size -- one ray per sample, a
     // strip's 64 lanes counted for each of its samples, walked or decided by the pixel's bounds --
@@ -2243,15 +2468,22 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
                 break;
             }
         }
-        const uint32_t rows_per_group = static_cast<uint32_t>(kTileH) >> split_log2;
-        const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + rows_per_group - 1) / rows_per_group);
         // a sphere of (nearly) no radius has no usable 1/r: it goes through the list variant
         const bool one = single_sphere_camera_pass(b);
+        // one sphere: a workgroup may own a 16x16 tile and render its strips in rounds (camera_body)
+        // (measured on the 4K 1024-sample frame: the fast build's whole frame 0.55 -> 0.52 ms and half of it
+        // 0.333 -> 0.318 ms with tiles, but an eighth 0.111 -> 0.137 ms -- four times fewer, four
+        // times longer waves leave a short launch's tail emptier -- and the exact build, whose
+        // waves are long as it is, loses 5 % on the whole frame and half as much again on an eighth)
+        const bool tiled = one && !exact && static_cast<uint64_t>(vc.width) * vc.row_count >= (1ull << 22);
+        const uint32_t rows_per_group = tiled ? static_cast<uint32_t>(kTileH) : static_cast<uint32_t>(kTileH) >> split_log2;
+        const uint32_t split_arg = split_log2 | (tiled ? kCameraTiled : 0u);
+        const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + rows_per_group - 1) / rows_per_group);
         const bool fold = (vc.flags & kFlagFoldScreen) != 0;
 #define AEHIP_LAUNCH_CAMERA(E, O, F, A)                                                                                \
     do {                                                                                                               \
         func = reinterpret_cast<const void *>(camera_kernel<E, O, F, A>);                                              \
-        hipLaunchKernelGGL((camera_kernel<E, O, F, A>), grid, dim3(kBlock), 0, stream, vc, b->cc, split_log2,          \
+        hipLaunchKernelGGL((camera_kernel<E, O, F, A>), grid, dim3(kBlock), 0, stream, vc, b->cc, split_arg,           \
                            b->d_geom, b->d_sample_terms, argb_dev, rgba, (E) && (O) && (F) && !(vc.flags & AEHIP_FLAG_WALK_ALL) ? b->d_row_miss : nullptr); \
     } while(0)
         // one ray per sample, whether the sample loop walks it or the pixel's bounds decide it; a
@@ -2276,9 +2508,9 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
                 const uint32_t per_group = 64u * (static_cast<uint32_t>(kBlock / 64) >> split_log2);
                 const uint32_t list_groups = (last - first + per_group - 1u) / per_group;
                 const dim3 line(list_groups + grid.x * grid.y);
-                if(fold && axial) { func = reinterpret_cast<const void *>(camera_hybrid_kernel<true, true>); hipLaunchKernelGGL((camera_hybrid_kernel<true, true>), line, dim3(kBlock), 0, stream, vc, b->cc, split_log2, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, grid.x); }
-                else if(fold) { func = reinterpret_cast<const void *>(camera_hybrid_kernel<true, false>); hipLaunchKernelGGL((camera_hybrid_kernel<true, false>), line, dim3(kBlock), 0, stream, vc, b->cc, split_log2, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, grid.x); }
-                else { func = reinterpret_cast<const void *>(camera_hybrid_kernel<false, false>); hipLaunchKernelGGL((camera_hybrid_kernel<false, false>), line, dim3(kBlock), 0, stream, vc, b->cc, split_log2, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, grid.x); }
+                if(fold && axial) { func = reinterpret_cast<const void *>(camera_hybrid_kernel<true, true>); hipLaunchKernelGGL((camera_hybrid_kernel<true, true>), line, dim3(kBlock), 0, stream, vc, b->cc, split_arg, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, grid.x); }
+                else if(fold) { func = reinterpret_cast<const void *>(camera_hybrid_kernel<true, false>); hipLaunchKernelGGL((camera_hybrid_kernel<true, false>), line, dim3(kBlock), 0, stream, vc, b->cc, split_arg, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, grid.x); }
+                else { func = reinterpret_cast<const void *>(camera_hybrid_kernel<false, false>); hipLaunchKernelGGL((camera_hybrid_kernel<false, false>), line, dim3(kBlock), 0, stream, vc, b->cc, split_arg, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, grid.x); }
             }
             else if(one && axial) AEHIP_LAUNCH_CAMERA(false, true, false, true);
             else if(one) AEHIP_LAUNCH_CAMERA(false, true, false, false);

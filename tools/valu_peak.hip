@@ -16,6 +16,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define HIPCHK(x)                                                                     \
@@ -96,6 +97,22 @@
     "v_fma_f32 v" #a ", v" #b ", v0, v" #a "\n"                                                                        \
     "v_add_f32 v" #a ", v" #a ", v0\n"
 
+// the hitting sample with no quarter-rate instruction at all: the hit distance refined from the
+// previous sample's by one Newton step on dd t^2 - 2 h t + c = 0 (T = t / 2, rho ~ 1 / sqrt(disc)
+// carried along and refined beside it); T and rho are carried from sample to sample (v7, v8)
+#define I_HIT_NEWTON_T(a, b, c)                                                                                        \
+    "v_add_f32 v" #b ", v" #c ", v" #b "\n"                                                                            \
+    "v_fma_f32 v0, v" #b ", v" #b ", v2\n"                                                                             \
+    "v_fma_f32 v3, v" #b ", v4, v5\n"                                                                                  \
+    "v_fma_f32 v6, v0, v7, -v3\n"                                                                                      \
+    "v_fma_f32 v0, v7, v6, v1\n"                                                                                       \
+    "v_fma_f32 v6, 2.0, v6, v3\n"                                                                                      \
+    "v_fma_f32 v6, v6, v8, 1.0\n"                                                                                      \
+    "v_fma_f32 v8, v8, v6, v8\n"                                                                                       \
+    "v_fma_f32 v7, v0, v8, v7\n"                                                                                       \
+    "v_fma_f32 v" #a ", v" #b ", v7, v" #a "\n"                                                                        \
+    "v_add_f32 v9, v9, v7\n"
+
 // what makes an instruction mix slower than its parts: one fully dependent chain; a destination that
 // is none of the sources; the hit mix with its two quarter-rate instructions replaced by adds
 #define I_FMA_CHAIN(a, b, c) "v_fma_f32 v16, v16, v" #b ", v" #c "\n"
@@ -140,7 +157,7 @@ struct stamp {
     __global__ __launch_bounds__(256) void NAME(stamp *out, int iters, float operand) {                              \
         unsigned long long t0, t1, r0, r1;                                                                             \
         asm volatile("v_mov_b32 v0, 1.0\n v_mov_b32 v1, 0x3a83126f\n v_mov_b32 v2, 0.5\n v_mov_b32 v3, 1.0\n"         \
-                     "v_mov_b32 v4, 0x3a83126f\n v_mov_b32 v5, 0.5\n v_mov_b32 v6, -1.0\n" ::: "v0", "v1", "v2", "v3", "v4", "v5", "v6"); \
+                     "v_mov_b32 v4, 0x3a83126f\n v_mov_b32 v5, 0.5\n v_mov_b32 v6, -1.0\n v_mov_b32 v7, 1.0\n v_mov_b32 v8, -1.0\n v_mov_b32 v9, 0\n" ::: "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9"); \
         asm volatile(                                                                                                  \
             "v_mov_b32 v16, 1.0\n v_mov_b32 v17, 1.0\n v_mov_b32 v18, 1.0\n v_mov_b32 v19, 1.0\n"                     \
             "v_mov_b32 v20, 1.0\n v_mov_b32 v21, 1.0\n v_mov_b32 v22, 1.0\n v_mov_b32 v23, 1.0\n"                     \
@@ -163,7 +180,7 @@ struct stamp {
         asm volatile("s_mov_b32 s20, %0\n s_mov_b32 s22, %1\n"                                                         \
                      "1:\n" BODY64 "s_sub_u32 s20, s20, 1\n s_cmp_lg_u32 s20, 0\n s_cbranch_scc1 1b\n"                 \
                      :: "s"(iters), "s"(operand)                                                                       \
-                     : "s20", "s22", "scc", "vcc", "v0", "v3", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", \
+                     : "s20", "s22", "scc", "vcc", "v0", "v3", "v6", "v7", "v8", "v9", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", \
                        "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43",      \
                        "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",      \
                        "v60", "v61", "v62", "v63");                                                                    \
@@ -197,6 +214,7 @@ PROBE_KERNEL(k_rcp_fma3, X4(ROT16(I_RCP_FMA3)))     // 64 groups of 4 instructio
 PROBE_KERNEL(k_camera_hit, ROT16(I_HIT))            // 16 samples x 9 instructions = 144 per iteration
 PROBE_KERNEL(k_camera_hit_grouped, X4(HIT_GROUPED))
 PROBE_KERNEL(k_camera_hit_newton, ROT16(I_HIT_NEWTON))      // 16 samples x 10 instructions
+PROBE_KERNEL(k_camera_hit_newton_t, ROT16(I_HIT_NEWTON_T))  // 16 samples x 11 instructions
 PROBE_KERNEL(k_rcp_fma1, X4(ROT16(I_RCP_FMA1)))
 PROBE_KERNEL(k_rcp_fma7, ROT16(I_RCP_FMA7))
 PROBE_KERNEL(k_rcp_fma15, ROT16(I_RCP_FMA15))
@@ -255,7 +273,10 @@ MFMA_KERNEL(k_mfma_f32_32fma)
 
 typedef void (*probe_fn)(stamp *, int, float);
 
+const char *g_only = nullptr;       // with an argument: only the probes whose name contains it
+
 void run(const char *name, probe_fn fn, int per_iteration, double flop_per_lane_op, int cus, double realtime_hz, stamp *d_out) {
+    if(g_only && !std::strstr(name, g_only)) return;
     for(int waves_per_simd : {1, 2, 4, 8}) {
         const int blocks = cus * waves_per_simd;         // 256 threads = 4 waves, one per SIMD of a CU
         const int n_waves = blocks * 4;
@@ -291,7 +312,8 @@ void run(const char *name, probe_fn fn, int per_iteration, double flop_per_lane_
     }
 }
 
-int main() {
+int main(int argc, char **argv) {
+    if(argc > 1) g_only = argv[1];
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, 0));
     int wall_khz = 0;
@@ -325,6 +347,7 @@ int main() {
     run("camera_hit_mix", k_camera_hit, 144, 13.0 / 9.0, cus, hz, d_out);
     run("camera_hit_by_4", k_camera_hit_grouped, 144, 13.0 / 9.0, cus, hz, d_out);
     run("camera_hit_newton", k_camera_hit_newton, 160, 16.0 / 10.0, cus, hz, d_out);
+    run("camera_hit_newton_t", k_camera_hit_newton_t, 176, 20.0 / 11.0, cus, hz, d_out);
     run("rcp+1fma", k_rcp_fma1, 128, 1.5, cus, hz, d_out);
     run("rcp+7fma", k_rcp_fma7, 128, 15.0 / 8.0, cus, hz, d_out);
     run("rcp+15fma", k_rcp_fma15, 256, 31.0 / 16.0, cus, hz, d_out);
