@@ -203,6 +203,10 @@ def frame_flops(paths, pixels):
 
 def main():
     args = parse()
+    # stdout carries the one JSON line and nothing else: libraries that write to file descriptor 1
+    # (RCCL prints a version banner when its first communicator comes up) go to stderr instead
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     if args.watchdog > 0:
         # a rank stuck in a collective leaves a stack trace and ends instead of holding the node
         import faulthandler
@@ -406,7 +410,7 @@ def main():
             line["aux"] = aux_measurements(rt, torch, stream, counters)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-        print(json.dumps(line), flush=True)
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
 
     if grouped:
         dist.destroy_process_group()

@@ -84,6 +84,31 @@ __host__ __device__ __forceinline__ uint32_t image_row(const view_consts &vc, ui
     return vc.row_begin + tile * vc.tile_stride + (row - tile * vc.tile_rows);
 }
 
+// Rows (of pixels, or of workgroups) in the order a launch takes them: from `start` outwards,
+// alternating sides.  The fast build's single-sphere launches start at the sphere, so the long
+// waves begin with the launch and the short ones -- background -- end it.
+__device__ __forceinline__ uint32_t outward_row(uint32_t i, uint32_t n, uint32_t start) {
+    const uint32_t below = start, above = n - 1u - start, both = min(below, above);
+    if(i <= 2u * both) return (i & 1u) ? start - ((i + 1u) >> 1) : start + (i >> 1);
+    return above > below ? i : n - 1u - i;
+}
+
+// the band row whose image row is nearest to y (inverse of image_row, clamped to the band)
+__host__ __device__ __forceinline__ uint32_t band_row_near(const view_consts &vc, float y) {
+    const float rel = y - static_cast<float>(vc.row_begin);
+    if(!(rel > 0.0f)) return 0u;
+    uint32_t row;
+    if(vc.tile_rows == 0) {
+        row = rel >= 4.0e9f ? 0xffffffffu : static_cast<uint32_t>(rel);
+    } else {
+        const uint32_t r = rel >= 4.0e9f ? 0xffffffffu : static_cast<uint32_t>(rel);
+        const uint32_t tile = r / vc.tile_stride, in_tile = r - tile * vc.tile_stride;
+        const uint64_t wide = static_cast<uint64_t>(tile) * vc.tile_rows + (in_tile < vc.tile_rows ? in_tile : vc.tile_rows - 1u);
+        row = wide > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(wide);
+    }
+    return row < vc.row_count ? row : vc.row_count - 1u;
+}
+
 // ------------------------------------------------------------------------------------------
 // arithmetic policy
 // ------------------------------------------------------------------------------------------
@@ -385,7 +410,7 @@ __device__ __forceinline__ f3 primary_pixel(const view_consts &vc, const camera_
 }
 
 template <bool EXACT, bool VEC4>
-__global__ __launch_bounds__(kPrimaryBlock) void primary_kernel(view_consts vc, camera_consts cc,
+__global__ __launch_bounds__(kPrimaryBlock) void primary_kernel(view_consts vc, camera_consts cc, uint32_t start_row,
                                                                  uint32_t *__restrict__ argb,
                                                                  float4 *__restrict__ rgba) {
     constexpr uint32_t PX = VEC4 ? 4u : 1u;
@@ -393,8 +418,9 @@ __global__ __launch_bounds__(kPrimaryBlock) void primary_kernel(view_consts vc, 
     const uint32_t gid = blockIdx.x * kPrimaryBlock + threadIdx.x;
     if(gid >= groups_per_row * vc.row_count) return;
 
-    const uint32_t row = gid / groups_per_row;
-    const uint32_t x0 = (gid - row * groups_per_row) * PX;
+    const uint32_t line = gid / groups_per_row;
+    const uint32_t x0 = (gid - line * groups_per_row) * PX;
+    const uint32_t row = outward_row(line, vc.row_count, start_row);
     const uint32_t y = image_row(vc, row);
     const f3 bg = row_background<EXACT>(vc, y);
 
@@ -1502,8 +1528,9 @@ __global__ __launch_bounds__(256) void ring_pixels_kernel(view_consts vc, camera
     }
 }
 
-// camera_body's split_and_tile argument: waves per strip (log2) in the low byte, and
+// camera_body's split_and_tile argument: waves per strip (log2) in the low byte,
 constexpr uint32_t kCameraTiled = 0x100u;      // a workgroup owns a 16x16 tile and renders its strips in rounds
+// and in the high half the row of workgroups the launch starts with (outward_row).
 
 // ------------------------------------------------------------------------------------------
 // camera pass: the path pass specialised for scenes in which every surface ends the path
@@ -1542,17 +1569,20 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
 
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
-    const uint32_t split_log2 = split_and_tile & 0xffu;
+    // A pixel's sample blocks are summed in `shares` interleaved shares (block b belongs to share
+    // b mod shares), and the shares are added in order.  Usually a strip's `shares` waves render
+    // one share each.  One sphere, rectangle launch, kCameraTiled: every wave renders a strip of
+    // its own, share after share -- same sums, same bits -- so the workgroup covers a 16x16 tile and
+    // its waves share nothing: no classes through LDS, no barrier, and a tile around which
+    // nothing is hit costs one short workgroup of busy waves instead of `shares` workgroups with
+    // one busy wave each.  (The exact build adds block sums in block order whatever the split.)
+    const uint32_t shares = 1u << (split_and_tile & 0xffu);
+    const bool tiled = ONE && pixel_list == nullptr && (split_and_tile & kCameraTiled) != 0u;
+    const uint32_t split_log2 = tiled ? 0u : (split_and_tile & 0xffu);
     const uint32_t split = 1u << split_log2;                    // waves per strip
     const uint32_t part = wave & (split - 1u);                  // this wave's place among the strip's waves
-    const uint32_t strips_per_round = kWaves >> split_log2;     // strips the workgroup renders side by side
-    // One sphere, rectangle launch, kCameraTiled: the workgroup owns a tile of kWaves strips (16x16
-    // pixels) and renders them in `split` rounds of strips_per_round.  A tile around which nothing
-    // is hit then costs one short workgroup of busy waves instead of `split` workgroups with one
-    // busy wave each; a tile full of hits keeps its waves `split` times as long.
-    const bool tiled = ONE && pixel_list == nullptr && (split_and_tile & kCameraTiled) != 0u;
-    const uint32_t rounds = tiled ? split : 1u;
-    const uint32_t strips_per_group = tiled ? kWaves : strips_per_round;
+    const uint32_t strip = wave >> split_log2;                  // strip of the workgroup
+    const uint32_t strips_per_group = kWaves >> split_log2;
     const f3 cam = {vc.cam[0], vc.cam[1], vc.cam[2]};
     const uint32_t n_spheres = ONE ? 1u : vc.n_spheres;
     const uint32_t nblocks = (vc.spp + AEHIP_SAMPLE_BLOCK - 1u) / AEHIP_SAMPLE_BLOCK;
@@ -1588,34 +1618,39 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
     //  - every sample hits, well conditioned, near root (fast build): a hit loop, which neither
     //    tests nor branches.
     // Everything else goes through the general loop.
-    // A strip is classified by one wave (a class costs about a hundred vector instructions): wave
-    // w takes strip w of a tile, otherwise the strip's first wave; it writes the strip at once
-    // when none of its pixels needs the sample loop; the classes reach the waves that render the
-    // strip through LDS.  Before that every wave tests the workgroup's whole rectangle: around
-    // most of the frame nothing can be hit, and the workgroup ends without classes or a barrier.
+    // A strip is classified by its first wave (a class costs about a hundred vector instructions),
+    // which writes the strip at once when none of its pixels needs the sample loop; the strip's
+    // other waves get the classes through LDS.  Before that every wave tests the workgroup's whole
+    // rectangle: around most of the frame nothing can be hit, and the workgroup ends without
+    // classes or a barrier.
     constexpr uint32_t kCulled = 1u, kSureHit = 2u, kListed = 4u, kNewton = 8u;
     __shared__ uint32_t s_class[ONE ? kWaves : 1][64];
     __shared__ uint32_t s_strip_work[kWaves];
-    bool classified = false;
+    uint32_t x = group_x * kTileW + (lane & 15u);
+    uint32_t row = (group_y * strips_per_group + strip) * 4u + (lane >> 4);
+    bool valid = (x < vc.width) && (row < vc.row_count);
+    if(pixel_list) {
+        const uint32_t entry = (group_x * strips_per_group + strip) * 64u + lane;
+        valid = entry < list_count;
+        const uint32_t packed = valid ? pixel_list[entry] : 0u;
+        x = packed & 0xffffu;
+        row = (packed >> 16) - list_row_bias;      // entries hold rows of the whole band; a launch may render part of it
+    }
+    const uint32_t y = image_row(vc, row);
+    bool culled = false, sure_hit = false, newton = false;
     if constexpr(ONE) {
         if(pixel_list == nullptr && (!EXACT || row_miss != nullptr)) {
-            classified = true;
-            const bool classifier = tiled || part == 0u;
-            const uint32_t cstrip = tiled ? wave : wave >> split_log2;
-            const uint32_t cx = group_x * kTileW + (lane & 15u);
-            const uint32_t crow = (group_y * strips_per_group + cstrip) * 4u + (lane >> 4);
-            const bool cvalid = classifier && (cx < vc.width) && (crow < vc.row_count);
-            const uint32_t cy = image_row(vc, crow);
             const uint32_t grow0 = group_y * strips_per_group * 4u;
             const uint32_t grow1 = min(grow0 + strips_per_group * 4u, vc.row_count);       // the grid has no workgroup past the last row
             if(!(vc.flags & AEHIP_FLAG_WALK_ALL) &&
                rectangle_misses(vc, cc, group_x * kTileW, min(group_x * kTileW + kTileW, vc.width), image_row(vc, grow0), image_row(vc, grow1 - 1u) + 1u)) {
-                if(cvalid) store_pixel(cx, crow, all_miss_total(cy));
+                if(valid && part == 0u) store_pixel(x, row, all_miss_total(y));
                 return;
             }
             uint32_t cls = 0;
-            if(classifier) {
-                const pixel_class pc = classify_pixel(vc, cc, cx, cy);
+            bool strip_work = false;
+            if(part == 0u) {
+                const pixel_class pc = classify_pixel(vc, cc, x, y);
                 if(SKIP_LISTED && pc.may_hit && !pc.well_conditioned) cls |= kListed;
                 if(!pc.may_hit) cls |= kCulled;
                 if constexpr(!EXACT) {
@@ -1623,14 +1658,30 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                         cls |= pc.faces_sphere ? (pc.newton_ok ? kNewton : kSureHit) : kCulled;    // behind the camera: no root counts
                 }
                 if(vc.flags & AEHIP_FLAG_WALK_ALL) cls &= kListed;      // every pixel through the general loop
-                s_class[cstrip][lane] = cls;
-                const bool strip_work = __ballot(cvalid && (cls & (kCulled | kListed)) == 0u) != 0ull;
-                if(lane == 0u) s_strip_work[cstrip] = strip_work ? 1u : 0u;
-                if(!strip_work && cvalid && (cls & kListed) == 0u) store_pixel(cx, crow, all_miss_total(cy));
+                strip_work = __ballot(valid && (cls & (kCulled | kListed)) == 0u) != 0ull;
+                if(!strip_work && valid && (cls & kListed) == 0u) store_pixel(x, row, all_miss_total(y));
             }
-            __syncthreads();
+            if(split == 1u) {
+                if(!strip_work) return;         // (no barrier follows in a workgroup whose waves share nothing)
+            } else {
+                if(part == 0u) {
+                    s_class[strip][lane] = cls;
+                    if(lane == 0u) s_strip_work[strip] = strip_work ? 1u : 0u;
+                }
+                __syncthreads();
+                cls = s_class[strip][lane];
+                uint32_t any = 0;
+                for(uint32_t i = 0; i < strips_per_group; i++) any |= s_strip_work[i];
+                if(any == 0u) return;           // every strip of the workgroup has been written
+                strip_work = s_strip_work[strip] != 0u;
+            }
+            valid = valid && (cls & kListed) == 0u && strip_work;
+            culled = (cls & kCulled) != 0u;
+            sure_hit = (cls & kSureHit) != 0u;
+            newton = (cls & kNewton) != 0u;
         }
     }
+    const bool work = valid && !culled;
 
     if constexpr(!ONE) {
         for(uint32_t i = tid; i < n_spheres; i += kBlock) {
@@ -1643,306 +1694,284 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
         __syncthreads();
     }
 
-    for(uint32_t round = 0; round < rounds; round++) {
-        const uint32_t strip = round * strips_per_round + (wave >> split_log2);     // strip of the workgroup
-        uint32_t x = group_x * kTileW + (lane & 15u);
-        uint32_t row = (group_y * strips_per_group + strip) * 4u + (lane >> 4);
-        bool valid = (x < vc.width) && (row < vc.row_count);
-        if(pixel_list) {
-            const uint32_t entry = (group_x * strips_per_round + strip) * 64u + lane;
-            valid = entry < list_count;
-            const uint32_t packed = valid ? pixel_list[entry] : 0u;
-            x = packed & 0xffffu;
-            row = (packed >> 16) - list_row_bias;      // entries hold rows of the whole band; a launch may render part of it
-        }
-        const uint32_t y = image_row(vc, row);
-        bool culled = false, sure_hit = false, newton = false;
-        if constexpr(ONE) {
-            if(classified) {
-                // a round none of whose strips has a pixel in the sample loop (their classifiers wrote them)
-                uint32_t any = 0;
-                for(uint32_t i = 0; i < strips_per_round; i++) any |= s_strip_work[round * strips_per_round + i];
-                if(any == 0u) continue;
-                const uint32_t cls = s_class[strip][lane];
-                valid = valid && (cls & kListed) == 0u && s_strip_work[strip] != 0u;
-                culled = (cls & kCulled) != 0u;
-                sure_hit = (cls & kSureHit) != 0u;
-                newton = (cls & kNewton) != 0u;
-            }
-        }
-        const bool work = valid && !culled;
+    (void)sample_terms;     // every path of this pass ends at its first hit: no path ever draws a random number
+    const f3 bg = row_background<EXACT>(vc, y);
+    const uint32_t pix_term = pixel_term(vc.seed_hash, y * vc.width + x);
+    // Sample positions (see sample_offset): the pixel's samples sit on a grid, the cell index is
+    // the same in every lane, and a row of cells shares its vertical position.  So the sample loop
+    // runs row by row: what depends on the row (the ray's v coordinate and everything built from
+    // it) is worked out once per row, and going to the next cell is one vector add.
+    const bool jitter = (vc.flags & AEHIP_FLAG_JITTER) != 0;
+    const pixel_offset off = offset_of_pixel(pix_term);
+    const float xf = static_cast<float>(x), yf = static_cast<float>(y);
+    const float dz = 0.0f - cam.z;
+    const float dz2 = dz * dz;
+    const uint32_t row_cells = 1u << vc.row_bits;
+    // the ray's viewport offsets of a sample at (jx, jy) in the pixel, folded into one fma per coordinate:
+    // u = ux0 + psx * jx, v = uy0 + psy * jy
+    const float ux0 = __builtin_fmaf(xf, vc.psx, -(vc.vw_half + cam.x));
+    const float uy0 = __builtin_fmaf(yf, vc.psy, -(vc.vh_half + cam.y));
 
-        (void)sample_terms;     // every path of this pass ends at its first hit: no path ever draws a random number
-        const f3 bg = row_background<EXACT>(vc, y);
-        const uint32_t pix_term = pixel_term(vc.seed_hash, y * vc.width + x);
-        // Sample positions (see sample_offset): the pixel's samples sit on a grid, the cell index is
-        // the same in every lane, and a row of cells shares its vertical position.  So the sample loop
-        // runs row by row: what depends on the row (the ray's v coordinate and everything built from
-        // it) is worked out once per row, and going to the next cell is one vector add.
-        const bool jitter = (vc.flags & AEHIP_FLAG_JITTER) != 0;
-        const pixel_offset off = offset_of_pixel(pix_term);
-        const float xf = static_cast<float>(x), yf = static_cast<float>(y);
-        const float dz = 0.0f - cam.z;
-        const float dz2 = dz * dz;
-        const uint32_t row_cells = 1u << vc.row_bits;
-        // the ray's viewport offsets of a sample at (jx, jy) in the pixel, folded into one fma per coordinate:
-        // u = ux0 + psx * jx, v = uy0 + psy * jy
-        const float ux0 = __builtin_fmaf(xf, vc.psx, -(vc.vw_half + cam.x));
-        const float uy0 = __builtin_fmaf(yf, vc.psy, -(vc.vh_half + cam.y));
+    // One sphere: the discriminant h*h - dd*c of the unnormalised ray (u, v, dz) is a quadratic in
+    // (u, v) with the coefficients of camera_consts; along a row of cells v is fixed and
+    //   disc(u) = u * (q_uu * u + B) + C,   B = q_uv v + q_u,   C = v (q_vv v + q_v) + q_0:
+    // two fmas per sample.  Every term of the expansion is at most a few times
+    // M = h*h + dd*(oc.oc + r*r), so this evaluation is, like the direct one, within a few dozen
+    // unit roundoffs of M of the real value.  The exact build screens with it: its constant term
+    // takes the margin times an upper bound of M over the pixel (all terms taken positive at the
+    // corner of the pixel farthest from the axes).
+    float screen_margin = 0.0f;
+    if constexpr(ONE && EXACT) {
+        const float ua = fmaxf(fabsf(ux0), fabsf(ux0 + vc.psx));
+        const float va = fmaxf(fabsf(uy0), fabsf(uy0 + vc.psy));
+        const float hmax = __builtin_fmaf(ua, fabsf(cc.oc[0]), __builtin_fmaf(va, fabsf(cc.oc[1]), fabsf(dz * cc.oc[2])));
+        const float ddmax = __builtin_fmaf(ua, ua, __builtin_fmaf(va, va, dz2));
+        screen_margin = (kScreenMargin * 1.001f) * __builtin_fmaf(ddmax, cc.magnitude, hmax * hmax);
+    }
 
-        // One sphere: the discriminant h*h - dd*c of the unnormalised ray (u, v, dz) is a quadratic in
-        // (u, v) with the coefficients of camera_consts; along a row of cells v is fixed and
-        //   disc(u) = u * (q_uu * u + B) + C,   B = q_uv v + q_u,   C = v (q_vv v + q_v) + q_0:
-        // two fmas per sample.  Every term of the expansion is at most a few times
-        // M = h*h + dd*(oc.oc + r*r), so this evaluation is, like the direct one, within a few dozen
-        // unit roundoffs of M of the real value.  The exact build screens with it: its constant term
-        // takes the margin times an upper bound of M over the pixel (all terms taken positive at the
-        // corner of the pixel farthest from the axes).
-        float screen_margin = 0.0f;
-        if constexpr(ONE && EXACT) {
-            const float ua = fmaxf(fabsf(ux0), fabsf(ux0 + vc.psx));
-            const float va = fmaxf(fabsf(uy0), fabsf(uy0 + vc.psy));
-            const float hmax = __builtin_fmaf(ua, fabsf(cc.oc[0]), __builtin_fmaf(va, fabsf(cc.oc[1]), fabsf(dz * cc.oc[2])));
-            const float ddmax = __builtin_fmaf(ua, ua, __builtin_fmaf(va, va, dz2));
-            screen_margin = (kScreenMargin * 1.001f) * __builtin_fmaf(ddmax, cc.magnitude, hmax * hmax);
-        }
-
-        // a row of cells inside the sample range [s, s_end): which cells, and where they sit
-        struct cell_row {
-            uint32_t count;         // cells of the row inside the range
-            uint32_t first_cell;    // index of the first of them
-            uint32_t cells;         // cells in the whole row
-            float first;            // first_cell as a float
-            float inv_cells;        // 1 / cells (exact for a full row)
-            float jy;               // vertical position of the row's samples in the pixel
-        };
-        // (the integers are the same in every lane; saying so keeps the sample loops' counters and
-        // branches in the scalar unit wherever the loops sit)
-        auto row_at = [&](uint32_t s, uint32_t s_end) {
-            cell_row cr;
-            if(!jitter) {           // every sample at the pixel centre: one "row" for the whole range
-                cr.count = __builtin_amdgcn_readfirstlane(s_end - s);
-                cr.first_cell = 0u;
-                cr.cells = 1u;
-                cr.first = 0.0f;
-                cr.inv_cells = 0.0f;
-                cr.jy = 0.5f;
-                return cr;
-            }
-            const uint32_t r = __builtin_amdgcn_readfirstlane(s >> vc.row_bits);
-            const uint32_t n_r = __builtin_amdgcn_readfirstlane(cells_in_row(vc, r));
-            cr.count = __builtin_amdgcn_readfirstlane(min(s_end, (r << vc.row_bits) + n_r) - s);
-            cr.first_cell = __builtin_amdgcn_readfirstlane(s & (row_cells - 1u));
-            cr.cells = n_r;
-            cr.first = static_cast<float>(cr.first_cell);
-            // (a power of two in all rows but a ragged last one: its reciprocal comes from the exponent,
-            // in the scalar unit, instead of a division)
-            cr.inv_cells = (n_r & (n_r - 1u)) == 0u ? __uint_as_float((127u - static_cast<uint32_t>(__builtin_ctz(n_r))) << 23)
-                                                    : __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(1.0f / static_cast<float>(n_r))));
-            cr.jy = (static_cast<float>(r << vc.row_bits) + off.ry * static_cast<float>(n_r)) * vc.inv_spp;
+    // a row of cells inside the sample range [s, s_end): which cells, and where they sit
+    struct cell_row {
+        uint32_t count;         // cells of the row inside the range
+        uint32_t first_cell;    // index of the first of them
+        uint32_t cells;         // cells in the whole row
+        float first;            // first_cell as a float
+        float inv_cells;        // 1 / cells (exact for a full row)
+        float jy;               // vertical position of the row's samples in the pixel
+    };
+    // (the integers are the same in every lane; saying so keeps the sample loops' counters and
+    // branches in the scalar unit wherever the loops sit)
+    auto row_at = [&](uint32_t s, uint32_t s_end) {
+        cell_row cr;
+        if(!jitter) {           // every sample at the pixel centre: one "row" for the whole range
+            cr.count = __builtin_amdgcn_readfirstlane(s_end - s);
+            cr.first_cell = 0u;
+            cr.cells = 1u;
+            cr.first = 0.0f;
+            cr.inv_cells = 0.0f;
+            cr.jy = 0.5f;
             return cr;
-        };
+        }
+        const uint32_t r = __builtin_amdgcn_readfirstlane(s >> vc.row_bits);
+        const uint32_t n_r = __builtin_amdgcn_readfirstlane(cells_in_row(vc, r));
+        cr.count = __builtin_amdgcn_readfirstlane(min(s_end, (r << vc.row_bits) + n_r) - s);
+        cr.first_cell = __builtin_amdgcn_readfirstlane(s & (row_cells - 1u));
+        cr.cells = n_r;
+        cr.first = static_cast<float>(cr.first_cell);
+        // (a power of two in all rows but a ragged last one: its reciprocal comes from the exponent,
+        // in the scalar unit, instead of a division)
+        cr.inv_cells = (n_r & (n_r - 1u)) == 0u ? __uint_as_float((127u - static_cast<uint32_t>(__builtin_ctz(n_r))) << 23)
+                                                : __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(1.0f / static_cast<float>(n_r))));
+        cr.jy = (static_cast<float>(r << vc.row_bits) + off.ry * static_cast<float>(n_r)) * vc.inv_spp;
+        return cr;
+    };
 
-        f3 sum = {0.0f, 0.0f, 0.0f};
+    f3 sum = {0.0f, 0.0f, 0.0f};
 
-        auto write_pixel = [&]() {
-            if(valid && part == 0u) {
-                if constexpr(EXACT && ONE) {
-                    if(culled) sum = all_miss_total(y);
-                }
-                store_pixel(x, row, sum);
+    auto write_pixel = [&]() {
+        if(valid && part == 0u) {
+            if constexpr(EXACT && ONE) {
+                if(culled) sum = all_miss_total(y);
             }
-        };
+            store_pixel(x, row, sum);
+        }
+    };
 
-        if constexpr(EXACT) {
-            for(uint32_t first = 0; first < nblocks; first += split) {      // a round: `split` consecutive blocks
-                const uint32_t blk = first + part;
-                f3 block = {0.0f, 0.0f, 0.0f};
-                if(blk < nblocks && work) {
-                    const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
-                    const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
-                    for(uint32_t s = s0; s < s1;) {
-                        const cell_row cr = row_at(s, s1);
-                        s += cr.count;
-                        // the row's part of the sample's ray exactly as the reference builds it
-                        // (src/software_raytracer.cpp:218-221), and of the folded screening ray
-                        const float py = yf + cr.jy;
-                        const float draw_y = (py * vc.psy - vc.vh_half) - cam.y;
-                        const float v = __builtin_fmaf(cr.jy, vc.psy, uy0);
-                        const float du = vc.psx * cr.inv_cells;
-                        const float u_first = __builtin_fmaf(jitter ? off.rx * cr.inv_cells : 0.5f, vc.psx, ux0);
-                        float qb = 0.0f, qc = 0.0f;
+    if constexpr(EXACT) {
+        for(uint32_t first = 0; first < nblocks; first += split) {      // a round: `split` consecutive blocks
+            const uint32_t blk = first + part;
+            f3 block = {0.0f, 0.0f, 0.0f};
+            if(blk < nblocks && work) {
+                const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
+                const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
+                for(uint32_t s = s0; s < s1;) {
+                    const cell_row cr = row_at(s, s1);
+                    s += cr.count;
+                    // the row's part of the sample's ray exactly as the reference builds it
+                    // (src/software_raytracer.cpp:218-221), and of the folded screening ray
+                    const float py = yf + cr.jy;
+                    const float draw_y = (py * vc.psy - vc.vh_half) - cam.y;
+                    const float v = __builtin_fmaf(cr.jy, vc.psy, uy0);
+                    const float du = vc.psx * cr.inv_cells;
+                    const float u_first = __builtin_fmaf(jitter ? off.rx * cr.inv_cells : 0.5f, vc.psx, ux0);
+                    float qb = 0.0f, qc = 0.0f;
+                    if constexpr(ONE && FOLD) {
+                        qb = __builtin_fmaf(cc.q_uv, v, cc.q_u);
+                        qc = __builtin_fmaf(v, __builtin_fmaf(cc.q_vv, v, cc.q_v), cc.q_0) + screen_margin;
+                    }
+                    float cell = cr.first;
+                    for(uint32_t k = 0; k < cr.count; k++, cell += 1.0f) {
+                        // Conservative miss test on the unnormalised ray in fused arithmetic.  With
+                        // h = draw.oc and dd = draw.draw the reference's discriminant has the sign of
+                        // h*h - dd*c.  Both evaluations are within about a dozen unit roundoffs of
+                        // h*h + dd*(oc.oc + r*r), so a value below -kScreenMargin of that magnitude is
+                        // negative in the exact evaluation as well, and the sample takes the row
+                        // background whatever its direction is.  Everything else runs the exact
+                        // arithmetic below.  Where the camera is not close to the viewport plane (host
+                        // check, kFlagFoldScreen) the screening ray comes from fmas instead of the
+                        // reference's operations: it differs from the exact ray by a few ulps of the
+                        // viewport extent, which moves the screening value by under 6e-6 of the
+                        // magnitude -- inside the margin with room to spare.
+                        auto exact_draw = [&]() {
+                            const float jx = jitter ? (cell + off.rx) * cr.inv_cells : 0.5f;
+                            const float px = xf + jx;
+                            return f3{(px * vc.psx - vc.vw_half) - cam.x, draw_y, dz};
+                        };
+                        f3 draw = {0.0f, 0.0f, dz};
+                        bool maybe = false;
                         if constexpr(ONE && FOLD) {
-                            qb = __builtin_fmaf(cc.q_uv, v, cc.q_u);
-                            qc = __builtin_fmaf(v, __builtin_fmaf(cc.q_vv, v, cc.q_v), cc.q_0) + screen_margin;
-                        }
-                        float cell = cr.first;
-                        for(uint32_t k = 0; k < cr.count; k++, cell += 1.0f) {
-                            // Conservative miss test on the unnormalised ray in fused arithmetic.  With
-                            // h = draw.oc and dd = draw.draw the reference's discriminant has the sign of
-                            // h*h - dd*c.  Both evaluations are within about a dozen unit roundoffs of
-                            // h*h + dd*(oc.oc + r*r), so a value below -kScreenMargin of that magnitude is
-                            // negative in the exact evaluation as well, and the sample takes the row
-                            // background whatever its direction is.  Everything else runs the exact
-                            // arithmetic below.  Where the camera is not close to the viewport plane (host
-                            // check, kFlagFoldScreen) the screening ray comes from fmas instead of the
-                            // reference's operations: it differs from the exact ray by a few ulps of the
-                            // viewport extent, which moves the screening value by under 6e-6 of the
-                            // magnitude -- inside the margin with room to spare.
-                            auto exact_draw = [&]() {
-                                const float jx = jitter ? (cell + off.rx) * cr.inv_cells : 0.5f;
-                                const float px = xf + jx;
-                                return f3{(px * vc.psx - vc.vw_half) - cam.x, draw_y, dz};
-                            };
-                            f3 draw = {0.0f, 0.0f, dz};
-                            bool maybe = false;
-                            if constexpr(ONE && FOLD) {
-                                const float u = __builtin_fmaf(cell, du, u_first);
-                                maybe = __builtin_fmaf(u, __builtin_fmaf(cc.q_uu, u, qb), qc) >= 0.0f;
-                            } else {
-                                float rx, ry;
-                                if constexpr(FOLD) {
-                                    rx = __builtin_fmaf(cell, du, u_first);
-                                    ry = v;
-                                } else {
-                                    draw = exact_draw();
-                                    rx = draw.x;
-                                    ry = draw.y;
-                                }
-                                const float dd = __builtin_fmaf(ry, ry, __builtin_fmaf(rx, rx, dz2));
-                                for(uint32_t i = 0; i < n_spheres; i++) {
-                                    const float4 kk = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
-                                    const float mag = ONE ? cc.magnitude : s_ctr[i].w;
-                                    const float h = __builtin_fmaf(ry, kk.y, __builtin_fmaf(rx, kk.x, dz * kk.z));
-                                    const float q = h * h;
-                                    const float screen = __builtin_fmaf(kScreenMargin, __builtin_fmaf(dd, mag, q), __builtin_fmaf(-dd, kk.w, q));
-                                    maybe = maybe || (screen >= 0.0f);
-                                }
-                            }
+                            const float u = __builtin_fmaf(cell, du, u_first);
+                            maybe = __builtin_fmaf(u, __builtin_fmaf(cc.q_uu, u, qb), qc) >= 0.0f;
+                        } else {
+                            float rx, ry;
                             if constexpr(FOLD) {
-                                if(maybe) draw = exact_draw();
+                                rx = __builtin_fmaf(cell, du, u_first);
+                                ry = v;
+                            } else {
+                                draw = exact_draw();
+                                rx = draw.x;
+                                ry = draw.y;
                             }
-
-                            f3 L = bg;
-                            if(maybe) {
-                                const f3 d = normalize3<true>(draw);
-                                const float a = dot3<true>(d, d);
-                                const float a4 = 4.0f * a;
-                                const float a2 = 2.0f * a;
-                                float closest = 3.402823466e+38f;
-                                int hit = -1;
-                                for(uint32_t i = 0; i < n_spheres; i++) {
-                                    const float4 kk = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
-                                    const float b = -2.0f * dot3<true>(d, f3{kk.x, kk.y, kk.z});
-                                    const float disc = b * b - a4 * kk.w;
-                                    if(disc >= 0.0f) {
-                                        // FAST_AFTER_DISC: up to here the sample is the reference's, bit for
-                                        // bit (ray, normalisation, discriminant -- where its rounding is
-                                        // amplified); from here on nothing amplifies, and the hardware's
-                                        // approximate square root and reciprocals are within 1e-6 of it
-                                        const float sq = FAST_AFTER_DISC ? __builtin_amdgcn_sqrtf(disc) : rt_sqrt<true>(disc);
-                                        const float inv_a2 = FAST_AFTER_DISC ? __builtin_amdgcn_rcpf(a2) : 0.0f;
-                                        float t = FAST_AFTER_DISC ? (-b - sq) * inv_a2 : (-b - sq) / a2;
-                                        bool ok = (t > kTMin) && (t < closest);
-                                        if(!ok) {
-                                            // rare (camera inside a sphere): keep it a branch -- computed
-                                            // unconditionally, the second IEEE division costs every hit 13 issue slots
-                                            asm volatile("");
-                                            t = FAST_AFTER_DISC ? (-b + sq) * inv_a2 : (-b + sq) / a2;
-                                            ok = (t > kTMin) && (t < closest);
-                                        }
-                                        if(ok) {
-                                            closest = t;
-                                            hit = static_cast<int>(i);
-                                        }
-                                    }
-                                }
-                                if(hit >= 0) {
-                                    const f3 ctr = ONE ? f3{cc.center[0], cc.center[1], cc.center[2]}
-                                                       : f3{s_ctr[hit].x, s_ctr[hit].y, s_ctr[hit].z};
-                                    if constexpr(FAST_AFTER_DISC) {
-                                        const f3 w = {__builtin_fmaf(d.x, closest, cam.x - ctr.x), __builtin_fmaf(d.y, closest, cam.y - ctr.y),
-                                                      __builtin_fmaf(d.z, closest, cam.z - ctr.z)};
-                                        const float half_inv = 0.5f * __builtin_amdgcn_rsqf(dot3<false>(w, w));
-                                        L = f3{__builtin_fmaf(w.x, half_inv, 0.5f), __builtin_fmaf(w.y, half_inv, 0.5f), __builtin_fmaf(w.z, half_inv, 0.5f)};
-                                    } else {
-                                        const f3 pt = {d.x * closest + cam.x, d.y * closest + cam.y, d.z * closest + cam.z};
-                                        const f3 n = normalize3<true>(f3{pt.x - ctr.x, pt.y - ctr.y, pt.z - ctr.z});
-                                        L = f3{remap_unit(n.x), remap_unit(n.y), remap_unit(n.z)};      // throughput is 1
-                                    }
-                                }
+                            const float dd = __builtin_fmaf(ry, ry, __builtin_fmaf(rx, rx, dz2));
+                            for(uint32_t i = 0; i < n_spheres; i++) {
+                                const float4 kk = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
+                                const float mag = ONE ? cc.magnitude : s_ctr[i].w;
+                                const float h = __builtin_fmaf(ry, kk.y, __builtin_fmaf(rx, kk.x, dz * kk.z));
+                                const float q = h * h;
+                                const float screen = __builtin_fmaf(kScreenMargin, __builtin_fmaf(dd, mag, q), __builtin_fmaf(-dd, kk.w, q));
+                                maybe = maybe || (screen >= 0.0f);
                             }
-                            block.x += L.x;
-                            block.y += L.y;
-                            block.z += L.z;
                         }
+                        if constexpr(FOLD) {
+                            if(maybe) draw = exact_draw();
+                        }
+
+                        f3 L = bg;
+                        if(maybe) {
+                            const f3 d = normalize3<true>(draw);
+                            const float a = dot3<true>(d, d);
+                            const float a4 = 4.0f * a;
+                            const float a2 = 2.0f * a;
+                            float closest = 3.402823466e+38f;
+                            int hit = -1;
+                            for(uint32_t i = 0; i < n_spheres; i++) {
+                                const float4 kk = ONE ? make_float4(cc.oc[0], cc.oc[1], cc.oc[2], cc.c) : s_occ[i];
+                                const float b = -2.0f * dot3<true>(d, f3{kk.x, kk.y, kk.z});
+                                const float disc = b * b - a4 * kk.w;
+                                if(disc >= 0.0f) {
+                                    // FAST_AFTER_DISC: up to here the sample is the reference's, bit for
+                                    // bit (ray, normalisation, discriminant -- where its rounding is
+                                    // amplified); from here on nothing amplifies, and the hardware's
+                                    // approximate square root and reciprocals are within 1e-6 of it
+                                    const float sq = FAST_AFTER_DISC ? __builtin_amdgcn_sqrtf(disc) : rt_sqrt<true>(disc);
+                                    const float inv_a2 = FAST_AFTER_DISC ? __builtin_amdgcn_rcpf(a2) : 0.0f;
+                                    float t = FAST_AFTER_DISC ? (-b - sq) * inv_a2 : (-b - sq) / a2;
+                                    bool ok = (t > kTMin) && (t < closest);
+                                    if(!ok) {
+                                        // rare (camera inside a sphere): keep it a branch -- computed
+                                        // unconditionally, the second IEEE division costs every hit 13 issue slots
+                                        asm volatile("");
+                                        t = FAST_AFTER_DISC ? (-b + sq) * inv_a2 : (-b + sq) / a2;
+                                        ok = (t > kTMin) && (t < closest);
+                                    }
+                                    if(ok) {
+                                        closest = t;
+                                        hit = static_cast<int>(i);
+                                    }
+                                }
+                            }
+                            if(hit >= 0) {
+                                const f3 ctr = ONE ? f3{cc.center[0], cc.center[1], cc.center[2]}
+                                                   : f3{s_ctr[hit].x, s_ctr[hit].y, s_ctr[hit].z};
+                                if constexpr(FAST_AFTER_DISC) {
+                                    const f3 w = {__builtin_fmaf(d.x, closest, cam.x - ctr.x), __builtin_fmaf(d.y, closest, cam.y - ctr.y),
+                                                  __builtin_fmaf(d.z, closest, cam.z - ctr.z)};
+                                    const float half_inv = 0.5f * __builtin_amdgcn_rsqf(dot3<false>(w, w));
+                                    L = f3{__builtin_fmaf(w.x, half_inv, 0.5f), __builtin_fmaf(w.y, half_inv, 0.5f), __builtin_fmaf(w.z, half_inv, 0.5f)};
+                                } else {
+                                    const f3 pt = {d.x * closest + cam.x, d.y * closest + cam.y, d.z * closest + cam.z};
+                                    const f3 n = normalize3<true>(f3{pt.x - ctr.x, pt.y - ctr.y, pt.z - ctr.z});
+                                    L = f3{remap_unit(n.x), remap_unit(n.y), remap_unit(n.z)};      // throughput is 1
+                                }
+                            }
+                        }
+                        block.x += L.x;
+                        block.y += L.y;
+                        block.z += L.z;
                     }
                 }
-                if(split == 1u) {
-                    sum.x += block.x;
-                    sum.y += block.y;
-                    sum.z += block.z;
-                } else {
-                    // hand the block sum to the strip's other waves; every wave adds the round's sums in
-                    // block order to its own copy of the total.  Two buffers alternate, so the barrier
-                    // of the next round also orders this round's reads before the buffer's next writes.
-                    const uint32_t buf = (first >> split_log2) & 1u;
-                    s_part[buf][wave][0][lane] = block.x;
-                    s_part[buf][wave][1][lane] = block.y;
-                    s_part[buf][wave][2][lane] = block.z;
-                    __syncthreads();
-                    const uint32_t live = min(split, nblocks - first);
-                    const uint32_t w0 = wave - part;       // the strip's first wave
-                    for(uint32_t p = 0; p < live; p++) {
-                        sum.x += s_part[buf][w0 + p][0][lane];
-                        sum.y += s_part[buf][w0 + p][1][lane];
-                        sum.z += s_part[buf][w0 + p][2][lane];
-                    }
+            }
+            if(split == 1u) {
+                sum.x += block.x;
+                sum.y += block.y;
+                sum.z += block.z;
+            } else {
+                // hand the block sum to the strip's other waves; every wave adds the round's sums in
+                // block order to its own copy of the total.  Two buffers alternate, so the barrier
+                // of the next round also orders this round's reads before the buffer's next writes.
+                const uint32_t buf = (first >> split_log2) & 1u;
+                s_part[buf][wave][0][lane] = block.x;
+                s_part[buf][wave][1][lane] = block.y;
+                s_part[buf][wave][2][lane] = block.z;
+                __syncthreads();
+                const uint32_t live = min(split, nblocks - first);
+                const uint32_t w0 = wave - part;       // the strip's first wave
+                for(uint32_t p = 0; p < live; p++) {
+                    sum.x += s_part[buf][w0 + p][0][lane];
+                    sum.y += s_part[buf][w0 + p][1][lane];
+                    sum.z += s_part[buf][w0 + p][2][lane];
                 }
             }
-        } else {
-            // fast build: the ray stays unnormalised (the hit test is scale invariant, t runs
-            // along `draw`); only hits add to the sum, misses are counted and added as
-            // (misses * background); the order of additions is free
-            uint32_t hits = 0;
-            f3 hit = {0.0f, 0.0f, 0.0f};        // the hit loop's sums, before the factor c * shade_scale
-            // the hit loop's two per-sample constants, in vector registers: an instruction with a
-            // scalar-register operand issues at half the rate of one without (measured, tools/valu_peak.hip)
-            float q_uu_v = 0.0f, oc_x_v = 0.0f, c4_v = 0.0f;
-            if constexpr(ONE) {
-                asm volatile("v_mov_b32 %0, %1" : "=v"(q_uu_v) : "s"(cc.q_uu));
-                asm volatile("v_mov_b32 %0, %1" : "=v"(oc_x_v) : "s"(cc.oc[0]));
-                asm volatile("v_mov_b32 %0, %1" : "=v"(c4_v) : "s"(0.25f * cc.c));
+        }
+    } else {
+        // fast build: the ray stays unnormalised (the hit test is scale invariant, t runs
+        // along `draw`); only hits add to the sum, misses are counted and added as
+        // (misses * background); the order of additions is free
+        uint32_t hits = 0;
+        f3 hit = {0.0f, 0.0f, 0.0f};        // the hit loop's sums, before the factor c * shade_scale
+        // the hit loop's two per-sample constants, in vector registers: an instruction with a
+        // scalar-register operand issues at half the rate of one without (measured, tools/valu_peak.hip)
+        float q_uu_v = 0.0f, oc_x_v = 0.0f, c4_v = 0.0f;
+        if constexpr(ONE) {
+            asm volatile("v_mov_b32 %0, %1" : "=v"(q_uu_v) : "s"(cc.q_uu));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(oc_x_v) : "s"(cc.oc[0]));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(c4_v) : "s"(0.25f * cc.c));
+        }
+        // The Newton hit loop's view of the pixel: T = t / 2 = c / (2 (h + sqrt(disc))) and
+        // rho = 1 / sqrt(disc) at the centre of the pixel with their gradients over the viewport.
+        // rho is used as that first-order expansion throughout the pixel; T's expansion only
+        // starts the rows (d disc / du = 2 (h oc.x - c u), likewise in v).
+        struct newton_pixel {
+            float u_c, v_c, rho_c, rho_u, rho_v, T_c, T_u, T_v;
+        };
+        newton_pixel np = {};
+        if constexpr(ONE) {
+            if(newton) {
+                np.u_c = __builtin_fmaf(0.5f, vc.psx, ux0);
+                np.v_c = __builtin_fmaf(0.5f, vc.psy, uy0);
+                const float h_c = __builtin_fmaf(np.u_c, cc.oc[0], __builtin_fmaf(np.v_c, cc.oc[1], dz * cc.oc[2]));
+                const float dd_c = __builtin_fmaf(np.u_c, np.u_c, __builtin_fmaf(np.v_c, np.v_c, dz2));
+                const float disc_c = __builtin_fmaf(-dd_c, cc.c, h_c * h_c);
+                np.rho_c = __builtin_amdgcn_rsqf(disc_c);
+                const float inv_w = __builtin_amdgcn_rcpf(__builtin_fmaf(disc_c, np.rho_c, h_c));
+                np.T_c = (0.5f * cc.c) * inv_w;
+                const float half_disc_u = __builtin_fmaf(h_c, cc.oc[0], -(cc.c * np.u_c));
+                const float half_disc_v = __builtin_fmaf(h_c, cc.oc[1], -(cc.c * np.v_c));
+                const float rho3 = -(np.rho_c * np.rho_c) * np.rho_c;
+                np.rho_u = rho3 * half_disc_u;
+                np.rho_v = rho3 * half_disc_v;
+                const float t_w = -np.T_c * inv_w;
+                np.T_u = t_w * __builtin_fmaf(np.rho_c, half_disc_u, cc.oc[0]);
+                np.T_v = t_w * __builtin_fmaf(np.rho_c, half_disc_v, cc.oc[1]);
             }
-            // The Newton hit loop's view of the pixel: T = t / 2 = c / (2 (h + sqrt(disc))) and
-            // rho = 1 / sqrt(disc) at the centre of the pixel with their gradients over the viewport.
-            // rho is used as that first-order expansion throughout the pixel; T's expansion only
-            // starts the rows (d disc / du = 2 (h oc.x - c u), likewise in v).
-            struct newton_pixel {
-                float u_c, v_c, rho_c, rho_u, rho_v, T_c, T_u, T_v;
-            };
-            newton_pixel np = {};
-            if constexpr(ONE) {
-                if(newton) {
-                    np.u_c = __builtin_fmaf(0.5f, vc.psx, ux0);
-                    np.v_c = __builtin_fmaf(0.5f, vc.psy, uy0);
-                    const float h_c = __builtin_fmaf(np.u_c, cc.oc[0], __builtin_fmaf(np.v_c, cc.oc[1], dz * cc.oc[2]));
-                    const float dd_c = __builtin_fmaf(np.u_c, np.u_c, __builtin_fmaf(np.v_c, np.v_c, dz2));
-                    const float disc_c = __builtin_fmaf(-dd_c, cc.c, h_c * h_c);
-                    np.rho_c = __builtin_amdgcn_rsqf(disc_c);
-                    const float inv_w = __builtin_amdgcn_rcpf(__builtin_fmaf(disc_c, np.rho_c, h_c));
-                    np.T_c = (0.5f * cc.c) * inv_w;
-                    const float half_disc_u = __builtin_fmaf(h_c, cc.oc[0], -(cc.c * np.u_c));
-                    const float half_disc_v = __builtin_fmaf(h_c, cc.oc[1], -(cc.c * np.v_c));
-                    const float rho3 = -(np.rho_c * np.rho_c) * np.rho_c;
-                    np.rho_u = rho3 * half_disc_u;
-                    np.rho_v = rho3 * half_disc_v;
-                    const float t_w = -np.T_c * inv_w;
-                    np.T_u = t_w * __builtin_fmaf(np.rho_c, half_disc_u, cc.oc[0]);
-                    np.T_v = t_w * __builtin_fmaf(np.rho_c, half_disc_v, cc.oc[1]);
-                }
-            }
-            for(uint32_t blk = part; blk < nblocks; blk += split) {
+        }
+        // this wave's shares of the pixel's blocks (one, or all of them one after the other), each summed apart
+        f3 shares_sum = {0.0f, 0.0f, 0.0f};
+        uint32_t shares_hits = 0;
+        for(uint32_t share = part; share < shares; share += split) {
+            sum = f3{0.0f, 0.0f, 0.0f};
+            hit = f3{0.0f, 0.0f, 0.0f};
+            hits = 0;
+            for(uint32_t blk = share; blk < nblocks; blk += shares) {
                 const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
                 const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
                 if constexpr(ONE) {
@@ -2157,38 +2186,48 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                 sum.y = __builtin_fmaf(hit.y, scale, sum.y);
                 sum.z = __builtin_fmaf(hit.z, scale, sum.z);
             }
-            if(split > 1u) {
-                s_part[0][wave][0][lane] = sum.x;
-                s_part[0][wave][1][lane] = sum.y;
-                s_part[0][wave][2][lane] = sum.z;
-                s_hits[wave][lane] = hits;
-                __syncthreads();
-                if(part == 0u) {
-                    for(uint32_t p = 1; p < split; p++) {
-                        sum.x += s_part[0][wave + p][0][lane];
-                        sum.y += s_part[0][wave + p][1][lane];
-                        sum.z += s_part[0][wave + p][2][lane];
-                        hits += s_hits[wave + p][lane];
-                    }
+            // (the first share as it is, the others added to it in order: what the strip's first wave does below with its partners' sums)
+            if(share == part) {
+                shares_sum = sum;
+                shares_hits = hits;
+            } else {
+                shares_sum.x += sum.x;
+                shares_sum.y += sum.y;
+                shares_sum.z += sum.z;
+                shares_hits += hits;
+            }
+        }
+        sum = shares_sum;
+        hits = shares_hits;
+        if(split > 1u) {
+            s_part[0][wave][0][lane] = sum.x;
+            s_part[0][wave][1][lane] = sum.y;
+            s_part[0][wave][2][lane] = sum.z;
+            s_hits[wave][lane] = hits;
+            __syncthreads();
+            if(part == 0u) {
+                for(uint32_t p = 1; p < split; p++) {
+                    sum.x += s_part[0][wave + p][0][lane];
+                    sum.y += s_part[0][wave + p][1][lane];
+                    sum.z += s_part[0][wave + p][2][lane];
+                    hits += s_hits[wave + p][lane];
                 }
             }
-            if constexpr(ONE) {
-                // constant parts of the hits' colours (see the sample loop)
-                const float hf = static_cast<float>(hits);
-                sum.x = __builtin_fmaf(hf, cc.shade_offset[0], sum.x);
-                sum.y = __builtin_fmaf(hf, cc.shade_offset[1], sum.y);
-                sum.z = __builtin_fmaf(hf, cc.shade_offset[2], dz * sum.z);
-            }
-            const float misses = static_cast<float>(vc.spp - hits);
-            sum.x = __builtin_fmaf(misses, bg.x, sum.x);
-            sum.y = __builtin_fmaf(misses, bg.y, sum.y);
-            sum.z = __builtin_fmaf(misses, bg.z, sum.z);
         }
-
-        write_pixel();
-        // the next round's waves reuse the hand-over buffers
-        if(rounds > 1u && split > 1u) __syncthreads();
+        if constexpr(ONE) {
+            // constant parts of the hits' colours (see the sample loop)
+            const float hf = static_cast<float>(hits);
+            sum.x = __builtin_fmaf(hf, cc.shade_offset[0], sum.x);
+            sum.y = __builtin_fmaf(hf, cc.shade_offset[1], sum.y);
+            sum.z = __builtin_fmaf(hf, cc.shade_offset[2], dz * sum.z);
+        }
+        const float misses = static_cast<float>(vc.spp - hits);
+        sum.x = __builtin_fmaf(misses, bg.x, sum.x);
+        sum.y = __builtin_fmaf(misses, bg.y, sum.y);
+        sum.z = __builtin_fmaf(misses, bg.z, sum.z);
     }
+
+    write_pixel();
 
     // (Ray and lane-slot counts of this pass follow from the image size -- one ray per sample, a
     // strip's 64 lanes counted for each of its samples, walked or decided by the pixel's bounds --
@@ -2201,8 +2240,8 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_c
                                                         const uint32_t *__restrict__ sample_terms,
                                                         uint32_t *__restrict__ argb, float4 *__restrict__ rgba,
                                                         const float4 *__restrict__ row_miss) {
-    camera_body<EXACT, ONE, FOLD, AXIAL, false>(vc, cc, split_log2, geom, sample_terms, argb, rgba, blockIdx.x, blockIdx.y, nullptr, 0u, 0u,
-                                                row_miss);
+    camera_body<EXACT, ONE, FOLD, AXIAL, false>(vc, cc, split_log2, geom, sample_terms, argb, rgba, blockIdx.x,
+                                                outward_row(blockIdx.y, gridDim.y, split_log2 >> 16), nullptr, 0u, 0u, row_miss);
 }
 
 // The exact build's value of a pixel whose samples all miss, before the division by spp: the row's
@@ -2247,8 +2286,9 @@ __global__ __launch_bounds__(kBlock, 8) void camera_hybrid_kernel(view_consts vc
                                                           list_count, list_row_bias, nullptr);
     } else {
         const uint32_t id = blockIdx.x - list_groups;
-        const uint32_t gy = id / groups_x;
-        camera_body<false, true, false, AXIAL, true>(vc, cc, split_log2, nullptr, sample_terms, argb, rgba, id - gy * groups_x, gy, nullptr, 0u, 0u,
+        const uint32_t line = id / groups_x;
+        const uint32_t gy = outward_row(line, (gridDim.x - list_groups) / groups_x, split_log2 >> 16);
+        camera_body<false, true, false, AXIAL, true>(vc, cc, split_log2, nullptr, sample_terms, argb, rgba, id - line * groups_x, gy, nullptr, 0u, 0u,
                                                      nullptr);
     }
 }
@@ -2435,6 +2475,15 @@ int build_ring_list(aehip_backend *b) {
     return AEHIP_OK;
 }
 
+// the band row nearest sphere 0's centre on the image (the band's middle row when the centre is behind the camera)
+uint32_t sphere_centre_row(const aehip_backend *b, const view_consts &vc) {
+    const float dz = 0.0f - vc.cam[2];
+    const float depth = b->cc.oc[2] * dz;
+    if(!(depth > 0.0f)) return vc.row_count / 2u;
+    const float v = b->cc.oc[1] * dz * dz / depth;          // the ray (u, v, dz) through the centre
+    return band_row_near(vc, (v + vc.vh_half + vc.cam[1]) / vc.psy);
+}
+
 int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t stream, const stream_scratch &scratch) {
     const view_consts &vc = b->vc;
     // Launches of one backend share one scratch: a launch that uses it (the streamed pass, the ray
@@ -2453,10 +2502,11 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         const bool vec4 = (vc.width % 4u) == 0 && (reinterpret_cast<uintptr_t>(argb_dev) % 16u) == 0;
         const uint64_t groups = static_cast<uint64_t>(vc.width / (vec4 ? 4u : 1u)) * vc.row_count;
         const dim3 grid(static_cast<uint32_t>((groups + kPrimaryBlock - 1) / kPrimaryBlock));
-        if(exact && vec4) { func = reinterpret_cast<const void *>(primary_kernel<true, true>); hipLaunchKernelGGL((primary_kernel<true, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba); }
-        else if(exact) { func = reinterpret_cast<const void *>(primary_kernel<true, false>); hipLaunchKernelGGL((primary_kernel<true, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba); }
-        else if(vec4) { func = reinterpret_cast<const void *>(primary_kernel<false, true>); hipLaunchKernelGGL((primary_kernel<false, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba); }
-        else { func = reinterpret_cast<const void *>(primary_kernel<false, false>); hipLaunchKernelGGL((primary_kernel<false, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba); }
+        const uint32_t start_row = sphere_centre_row(b, vc);
+        if(exact && vec4) { func = reinterpret_cast<const void *>(primary_kernel<true, true>); hipLaunchKernelGGL((primary_kernel<true, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, start_row, argb_dev, rgba); }
+        else if(exact) { func = reinterpret_cast<const void *>(primary_kernel<true, false>); hipLaunchKernelGGL((primary_kernel<true, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, start_row, argb_dev, rgba); }
+        else if(vec4) { func = reinterpret_cast<const void *>(primary_kernel<false, true>); hipLaunchKernelGGL((primary_kernel<false, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, start_row, argb_dev, rgba); }
+        else { func = reinterpret_cast<const void *>(primary_kernel<false, false>); hipLaunchKernelGGL((primary_kernel<false, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, start_row, argb_dev, rgba); }
     } else if(b->all_terminal && vc.n_spheres <= static_cast<uint32_t>(kLdsSpheres)) {
         // waves per strip: as many as divide the pixel's sample blocks evenly (or nearly so)
         const uint32_t nblocks = (vc.spp + AEHIP_SAMPLE_BLOCK - 1u) / AEHIP_SAMPLE_BLOCK;
@@ -2477,8 +2527,12 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         // waves are long as it is, loses 5 % on the whole frame and half as much again on an eighth)
         const bool tiled = one && !exact && static_cast<uint64_t>(vc.width) * vc.row_count >= (1ull << 22);
         const uint32_t rows_per_group = tiled ? static_cast<uint32_t>(kTileH) : static_cast<uint32_t>(kTileH) >> split_log2;
-        const uint32_t split_arg = split_log2 | (tiled ? kCameraTiled : 0u);
         const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + rows_per_group - 1) / rows_per_group);
+        // the row of workgroups the launch starts with: the one nearest the sphere's centre on the
+        // image in the fast build (measured 0.489 -> 0.478 ms a 4K frame; the exact build, whose
+        // background rows are not that much shorter than its others, measured no gain and keeps row 0)
+        const uint32_t start_group = one && !exact ? sphere_centre_row(b, vc) / rows_per_group : 0u;
+        const uint32_t split_arg = split_log2 | (tiled ? kCameraTiled : 0u) | (start_group << 16);
         const bool fold = (vc.flags & kFlagFoldScreen) != 0;
 #define AEHIP_LAUNCH_CAMERA(E, O, F, A)                                                                                \
     do {                                                                                                               \
