@@ -14,13 +14,19 @@ LIB := raytracer_amd/lib/libhip_raytracer.so
 CLI := raytracer_amd/bin/raytracer_hip
 HOST_SRCS := $(wildcard raytracer_amd/host/*.cpp)
 
-.PHONY: all lib host oracle tools clean
+.PHONY: all lib host oracle tools timeline clean
 all: lib host oracle tools
 
 lib: $(LIB)
 $(LIB): raytracer_amd/csrc/hip_raytracer_kernels.hip raytracer_amd/csrc/rt_exact_math.h include/hip_raytracer.h
 	@mkdir -p raytracer_amd/lib
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $<
+
+# measurement build of the library: per-wave start / end stamps of the fast camera launch (tools/wave_timeline.py)
+timeline: tools/bin/libhip_raytracer_timeline.so
+tools/bin/libhip_raytracer_timeline.so: raytracer_amd/csrc/hip_raytracer_kernels.hip raytracer_amd/csrc/rt_exact_math.h include/hip_raytracer.h
+	@mkdir -p tools/bin
+	$(HIPCC) $(HIPFLAGS) -DAEHIP_WAVE_TIMELINE -shared -o $@ $<
 
 # GPU-side self checks and microbenchmarks (run on the GPU box by tests / by hand)
 tools: raytracer_amd/bin/check_exact_math tools/bin/valu_peak

@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "hip_raytracer.h"
@@ -84,29 +85,20 @@ __host__ __device__ __forceinline__ uint32_t image_row(const view_consts &vc, ui
     return vc.row_begin + tile * vc.tile_stride + (row - tile * vc.tile_rows);
 }
 
-// Rows (of pixels, or of workgroups) in the order a launch takes them: from `start` outwards,
-// alternating sides.  The fast build's single-sphere launches start at the sphere, so the long
-// waves begin with the launch and the short ones -- background -- end it.
-__device__ __forceinline__ uint32_t outward_row(uint32_t i, uint32_t n, uint32_t start) {
-    const uint32_t below = start, above = n - 1u - start, both = min(below, above);
-    if(i <= 2u * both) return (i & 1u) ? start - ((i + 1u) >> 1) : start + (i >> 1);
-    return above > below ? i : n - 1u - i;
-}
-
-// the band row whose image row is nearest to y (inverse of image_row, clamped to the band)
-__host__ __device__ __forceinline__ uint32_t band_row_near(const view_consts &vc, float y) {
-    const float rel = y - static_cast<float>(vc.row_begin);
-    if(!(rel > 0.0f)) return 0u;
-    uint32_t row;
-    if(vc.tile_rows == 0) {
-        row = rel >= 4.0e9f ? 0xffffffffu : static_cast<uint32_t>(rel);
-    } else {
-        const uint32_t r = rel >= 4.0e9f ? 0xffffffffu : static_cast<uint32_t>(rel);
-        const uint32_t tile = r / vc.tile_stride, in_tile = r - tile * vc.tile_stride;
-        const uint64_t wide = static_cast<uint64_t>(tile) * vc.tile_rows + (in_tile < vc.tile_rows ? in_tile : vc.tile_rows - 1u);
-        row = wide > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(wide);
-    }
-    return row < vc.row_count ? row : vc.row_count - 1u;
+// Rows of workgroups in the order a camera launch takes them, given the rows [lo, hi] in which the
+// sphere can be hit (packed lo | hi << 16; hi < lo: plain order): lo, hi, lo + 1, hi - 1, ... inwards,
+// then the rows outside.  The rows at the sphere's upper and lower edge hold its slowest strips
+// (pixels of several classes, which walk their samples once per class) and the rows outside only
+// background: the longest waves start with the launch and the shortest end it.  (Timeline of a 4K
+// frame, tools/wave_timeline.py: taken top to bottom or centre outwards, the launch's last tenth
+// was a few dozen waves of the edge rows on an otherwise empty chip.)
+__device__ __forceinline__ uint32_t edges_first_row(uint32_t i, uint32_t packed) {
+    const uint32_t lo = packed & 0xffffu, hi = packed >> 16;
+    if(hi < lo) return i;
+    const uint32_t inside = hi - lo + 1u;
+    if(i < inside) return (i & 1u) ? hi - (i >> 1) : lo + (i >> 1);
+    const uint32_t j = i - inside;
+    return j < lo ? j : hi + 1u + (j - lo);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -410,7 +402,7 @@ __device__ __forceinline__ f3 primary_pixel(const view_consts &vc, const camera_
 }
 
 template <bool EXACT, bool VEC4>
-__global__ __launch_bounds__(kPrimaryBlock) void primary_kernel(view_consts vc, camera_consts cc, uint32_t start_row,
+__global__ __launch_bounds__(kPrimaryBlock) void primary_kernel(view_consts vc, camera_consts cc,
                                                                  uint32_t *__restrict__ argb,
                                                                  float4 *__restrict__ rgba) {
     constexpr uint32_t PX = VEC4 ? 4u : 1u;
@@ -418,9 +410,8 @@ __global__ __launch_bounds__(kPrimaryBlock) void primary_kernel(view_consts vc, 
     const uint32_t gid = blockIdx.x * kPrimaryBlock + threadIdx.x;
     if(gid >= groups_per_row * vc.row_count) return;
 
-    const uint32_t line = gid / groups_per_row;
-    const uint32_t x0 = (gid - line * groups_per_row) * PX;
-    const uint32_t row = outward_row(line, vc.row_count, start_row);
+    const uint32_t row = gid / groups_per_row;
+    const uint32_t x0 = (gid - row * groups_per_row) * PX;
     const uint32_t y = image_row(vc, row);
     const f3 bg = row_background<EXACT>(vc, y);
 
@@ -1395,6 +1386,7 @@ struct pixel_class {
     bool well_conditioned;      // every sample hits, with conditioning value q >= kExactBelowQ
     bool faces_sphere;          // h = draw.oc > 0 at the pixel (h keeps its sign over a pixel whose samples all hit)
     bool newton_ok;             // the hit distance may be carried from cell to cell by one Newton step (kNewtonTolerance)
+    bool newton_twice_ok;       // ... by two steps a cell
 };
 
 // The fast build's hit loop carries the hit distance t of the unnormalised ray along a row of
@@ -1471,7 +1463,12 @@ __device__ __forceinline__ pixel_class classify_pixel(const view_consts &vc, con
     const float start = dt + 0.25f * pixel_change * cells * dt;
     const float t_error = 2.0f * (eps * start + start * start * dd_max / (2.0f * s_min));
     // colour = draw * (shade_scale * t) + constant; false for NaN (s_min = 0, h_min <= 0 give inf or a negative bound)
-    pc.newton_ok = h_min > 0.0f && cc.c > 0.0f && eps <= 0.05f && cc.shade_scale * __builtin_sqrtf(dd_max) * t_error <= kNewtonTolerance;
+    const float colour_per_t = cc.shade_scale * __builtin_sqrtf(dd_max);
+    const bool sane = h_min > 0.0f && cc.c > 0.0f && eps <= 0.05f;
+    pc.newton_ok = sane && colour_per_t * t_error <= kNewtonTolerance;
+    // a second step starts where the first ended (t_error carries a factor 2 to spare already)
+    const float t_error_twice = 2.0f * (eps * t_error + t_error * t_error * dd_max / (2.0f * s_min));
+    pc.newton_twice_ok = sane && t_error <= 0.25f * start && colour_per_t * t_error_twice <= kNewtonTolerance;
     return pc;
 }
 
@@ -1528,9 +1525,32 @@ __global__ __launch_bounds__(256) void ring_pixels_kernel(view_consts vc, camera
     }
 }
 
-// camera_body's split_and_tile argument: waves per strip (log2) in the low byte,
+#ifdef AEHIP_WAVE_TIMELINE
+// Measurement build (make timeline; tools/wave_timeline.py): every wave of the fast build's
+// single-sphere launch leaves its start and end on the constant-rate clock and whether it
+// rendered listed pixels, indexed by workgroup and wave (no atomics: they would serialise).
+constexpr uint32_t kTimelineWaves = 1u << 18;
+__device__ unsigned long long g_timeline[kTimelineWaves * 3];
+__device__ unsigned int g_timeline_waves;
+struct timeline_stamp {
+    unsigned long long t0;
+    uint32_t kind;
+    __device__ ~timeline_stamp() {
+        if((threadIdx.x & 63u) == 0u) {
+            const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+            if(i < kTimelineWaves) {
+                g_timeline[3u * i] = t0;
+                g_timeline[3u * i + 1u] = __builtin_amdgcn_s_memrealtime();
+                g_timeline[3u * i + 2u] = kind;
+            }
+            if(i == 0u) g_timeline_waves = gridDim.x * (blockDim.x >> 6);
+        }
+    }
+};
+#endif
+
+// camera_body's split_and_tile argument: waves per strip (log2) in the low byte and
 constexpr uint32_t kCameraTiled = 0x100u;      // a workgroup owns a 16x16 tile and renders its strips in rounds
-// and in the high half the row of workgroups the launch starts with (outward_row).
 
 // ------------------------------------------------------------------------------------------
 // camera pass: the path pass specialised for scenes in which every surface ends the path
@@ -1623,7 +1643,7 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
     // other waves get the classes through LDS.  Before that every wave tests the workgroup's whole
     // rectangle: around most of the frame nothing can be hit, and the workgroup ends without
     // classes or a barrier.
-    constexpr uint32_t kCulled = 1u, kSureHit = 2u, kListed = 4u, kNewton = 8u;
+    constexpr uint32_t kCulled = 1u, kSureHit = 2u, kListed = 4u, kNewton = 8u, kNewtonTwice = 16u;
     __shared__ uint32_t s_class[ONE ? kWaves : 1][64];
     __shared__ uint32_t s_strip_work[kWaves];
     uint32_t x = group_x * kTileW + (lane & 15u);
@@ -1637,7 +1657,7 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
         row = (packed >> 16) - list_row_bias;      // entries hold rows of the whole band; a launch may render part of it
     }
     const uint32_t y = image_row(vc, row);
-    bool culled = false, sure_hit = false, newton = false;
+    bool culled = false, sure_hit = false, newton = false, newton_twice = false;
     if constexpr(ONE) {
         if(pixel_list == nullptr && (!EXACT || row_miss != nullptr)) {
             const uint32_t grow0 = group_y * strips_per_group * 4u;
@@ -1655,7 +1675,7 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                 if(!pc.may_hit) cls |= kCulled;
                 if constexpr(!EXACT) {
                     if(cc.near_root_only != 0u && pc.may_hit && pc.well_conditioned)
-                        cls |= pc.faces_sphere ? (pc.newton_ok ? kNewton : kSureHit) : kCulled;    // behind the camera: no root counts
+                        cls |= pc.faces_sphere ? (pc.newton_ok ? kNewton : pc.newton_twice_ok ? (kNewton | kNewtonTwice) : kSureHit) : kCulled;    // behind the camera: no root counts
                 }
                 if(vc.flags & AEHIP_FLAG_WALK_ALL) cls &= kListed;      // every pixel through the general loop
                 strip_work = __ballot(valid && (cls & (kCulled | kListed)) == 0u) != 0ull;
@@ -1679,6 +1699,7 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
             culled = (cls & kCulled) != 0u;
             sure_hit = (cls & kSureHit) != 0u;
             newton = (cls & kNewton) != 0u;
+            newton_twice = (cls & kNewtonTwice) != 0u;
         }
     }
     const bool work = valid && !culled;
@@ -2000,6 +2021,10 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                             nr.T = __builtin_fmaf(np.T_u, off_u, __builtin_fmaf(np.T_v, off_v, np.T_c));
                             return nr;
                         };
+                        // (TWICE: some pixel of the strip needs a second step a cell -- newton_twice; the
+                        // others keep their first step's value, so a pixel's arithmetic does not depend on its neighbours)
+                        auto walk_rows = [&](auto twice_tag) {
+                        constexpr bool TWICE = decltype(twice_tag)::value;
                         for(uint32_t s = s0; s < s1;) {
                             const cell_row cr = row_at(s, s1);
                             s += cr.count;
@@ -2030,6 +2055,13 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                                     const float f4_b = __builtin_fmaf(rb.T, __builtin_fmaf(dd_b, rb.T, -h_b), c4_v);
                                     ra.T = __builtin_fmaf(f4_a, ra.rho, ra.T);
                                     rb.T = __builtin_fmaf(f4_b, rb.rho, rb.T);
+                                    if constexpr(TWICE) {
+                                        const float g4_a = __builtin_fmaf(ra.T, __builtin_fmaf(dd_a, ra.T, -h_a), c4_v);
+                                        const float g4_b = __builtin_fmaf(rb.T, __builtin_fmaf(dd_b, rb.T, -h_b), c4_v);
+                                        const float again_a = __builtin_fmaf(g4_a, ra.rho, ra.T), again_b = __builtin_fmaf(g4_b, rb.rho, rb.T);
+                                        ra.T = newton_twice ? again_a : ra.T;
+                                        rb.T = newton_twice ? again_b : rb.T;
+                                    }
                                     scale_a += ra.T;
                                     scale_b += rb.T;
                                     hit.x = __builtin_fmaf(u, ra.T + rb.T, hit.x);
@@ -2047,6 +2079,11 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                                     const float h = __builtin_fmaf(u, oc_x_v, ra.h_row);
                                     const float f4 = __builtin_fmaf(ra.T, __builtin_fmaf(dd, ra.T, -h), c4_v);
                                     ra.T = __builtin_fmaf(f4, ra.rho, ra.T);
+                                    if constexpr(TWICE) {
+                                        const float g4 = __builtin_fmaf(ra.T, __builtin_fmaf(dd, ra.T, -h), c4_v);
+                                        const float again = __builtin_fmaf(g4, ra.rho, ra.T);
+                                        ra.T = newton_twice ? again : ra.T;
+                                    }
                                     hit.x = __builtin_fmaf(u, ra.T, hit.x);
                                     row_scale += ra.T;
                                 }
@@ -2055,6 +2092,9 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                                 hits += cr.count;
                             }
                         }
+                        };
+                        if(__ballot(newton_twice) != 0ull) walk_rows(std::true_type{});
+                        else walk_rows(std::false_type{});
                     }
                     if(sure_hit) {
                         // The hit loop: every sample of the pixel hits at the near root (see the
@@ -2235,13 +2275,13 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
 }
 
 template <bool EXACT, bool ONE, bool FOLD, bool AXIAL>
-__global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_consts cc, uint32_t split_log2,
+__global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_consts cc, uint32_t split_log2, uint32_t row_order,
                                                         const float4 *__restrict__ geom,
                                                         const uint32_t *__restrict__ sample_terms,
                                                         uint32_t *__restrict__ argb, float4 *__restrict__ rgba,
                                                         const float4 *__restrict__ row_miss) {
     camera_body<EXACT, ONE, FOLD, AXIAL, false>(vc, cc, split_log2, geom, sample_terms, argb, rgba, blockIdx.x,
-                                                outward_row(blockIdx.y, gridDim.y, split_log2 >> 16), nullptr, 0u, 0u, row_miss);
+                                                edges_first_row(blockIdx.y, row_order), nullptr, 0u, 0u, row_miss);
 }
 
 // The exact build's value of a pixel whose samples all miss, before the division by spp: the row's
@@ -2276,18 +2316,21 @@ __global__ __launch_bounds__(64) void row_miss_sums_kernel(view_consts vc, uint3
 // registers, one allocation step over what 8 waves leave each other, and the pass lives on its
 // occupancy -- measured 2.19 ms a frame at 7 waves against 2.06 at 8.)
 template <bool FOLD, bool AXIAL>
-__global__ __launch_bounds__(kBlock, 8) void camera_hybrid_kernel(view_consts vc, camera_consts cc, uint32_t split_log2,
+__global__ __launch_bounds__(kBlock, 8) void camera_hybrid_kernel(view_consts vc, camera_consts cc, uint32_t split_log2, uint32_t row_order,
                                                                const uint32_t *__restrict__ sample_terms,
                                                                uint32_t *__restrict__ argb, float4 *__restrict__ rgba,
                                                                const uint32_t *__restrict__ pixel_list, uint32_t list_count,
                                                                uint32_t list_row_bias, uint32_t list_groups, uint32_t groups_x) {
+#ifdef AEHIP_WAVE_TIMELINE
+    timeline_stamp stamp{__builtin_amdgcn_s_memrealtime(), blockIdx.x < list_groups ? 1u : 0u};
+#endif
     if(blockIdx.x < list_groups) {
         camera_body<true, true, FOLD, AXIAL, false, true>(vc, cc, split_log2, nullptr, sample_terms, argb, rgba, blockIdx.x, 0u, pixel_list,
                                                           list_count, list_row_bias, nullptr);
     } else {
         const uint32_t id = blockIdx.x - list_groups;
         const uint32_t line = id / groups_x;
-        const uint32_t gy = outward_row(line, (gridDim.x - list_groups) / groups_x, split_log2 >> 16);
+        const uint32_t gy = edges_first_row(line, row_order);
         camera_body<false, true, false, AXIAL, true>(vc, cc, split_log2, nullptr, sample_terms, argb, rgba, id - line * groups_x, gy, nullptr, 0u, 0u,
                                                      nullptr);
     }
@@ -2475,13 +2518,37 @@ int build_ring_list(aehip_backend *b) {
     return AEHIP_OK;
 }
 
-// the band row nearest sphere 0's centre on the image (the band's middle row when the centre is behind the camera)
-uint32_t sphere_centre_row(const aehip_backend *b, const view_consts &vc) {
-    const float dz = 0.0f - vc.cam[2];
-    const float depth = b->cc.oc[2] * dz;
-    if(!(depth > 0.0f)) return vc.row_count / 2u;
-    const float v = b->cc.oc[1] * dz * dz / depth;          // the ray (u, v, dz) through the centre
-    return band_row_near(vc, (v + vc.vh_half + vc.cam[1]) / vc.psy);
+// the band row whose image row is nearest to y (inverse of image_row, clamped to the band)
+uint32_t band_row_near(const view_consts &vc, double y) {
+    const double rel = y - static_cast<double>(vc.row_begin);
+    if(!(rel > 0.0)) return 0u;
+    const uint64_t r = rel >= 4.0e9 ? 0xffffffffull : static_cast<uint64_t>(rel);
+    uint64_t row = r;
+    if(vc.tile_rows != 0) {
+        const uint64_t tile = r / vc.tile_stride, in_tile = r - tile * vc.tile_stride;
+        row = tile * vc.tile_rows + std::min<uint64_t>(in_tile, vc.tile_rows - 1u);
+    }
+    return static_cast<uint32_t>(std::min<uint64_t>(row, vc.row_count - 1u));
+}
+
+// Rows of workgroups (rows_per_group band rows each) between which sphere 0 can be hit, packed
+// lo | hi << 16 for edges_first_row; 1 (hi < lo: plain order) when there is no such range to
+// speak of.  For a ray (u, v, dz) the discriminant is a quadratic in (u, v) (camera_consts); its
+// largest value along u is non-negative between two values of v, the sphere's upper and lower
+// edge on the viewport.
+uint32_t sphere_group_rows(const aehip_backend *b, const view_consts &vc, uint32_t rows_per_group, uint32_t groups) {
+    const camera_consts &cc = b->cc;
+    const double quu = cc.q_uu, quv = cc.q_uv, qvv = cc.q_vv, qu = cc.q_u, qv = cc.q_v, q0 = cc.q_0;
+    if(!(quu < 0.0)) return 1u;                             // (the camera is not outside the sphere)
+    const double a2 = quv * quv - 4.0 * quu * qvv, a1 = 2.0 * quv * qu - 4.0 * quu * qv, a0 = qu * qu - 4.0 * quu * q0;
+    const double d = a1 * a1 - 4.0 * a2 * a0;
+    if(!(a2 < 0.0) || !(d > 0.0)) return 1u;
+    const double root = std::sqrt(d);
+    const double v_lo = (-a1 + root) / (2.0 * a2), v_hi = (-a1 - root) / (2.0 * a2);       // a2 < 0: v_lo < v_hi
+    const double to_row = 1.0 / static_cast<double>(vc.psy), shift = static_cast<double>(vc.vh_half) + static_cast<double>(vc.cam[1]);
+    const uint32_t lo = band_row_near(vc, (v_lo + shift) * to_row - 1.0) / rows_per_group;
+    const uint32_t hi = std::min(band_row_near(vc, (v_hi + shift) * to_row + 1.0) / rows_per_group, groups - 1u);
+    return hi < lo ? 1u : lo | (hi << 16);
 }
 
 int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t stream, const stream_scratch &scratch) {
@@ -2502,11 +2569,10 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         const bool vec4 = (vc.width % 4u) == 0 && (reinterpret_cast<uintptr_t>(argb_dev) % 16u) == 0;
         const uint64_t groups = static_cast<uint64_t>(vc.width / (vec4 ? 4u : 1u)) * vc.row_count;
         const dim3 grid(static_cast<uint32_t>((groups + kPrimaryBlock - 1) / kPrimaryBlock));
-        const uint32_t start_row = sphere_centre_row(b, vc);
-        if(exact && vec4) { func = reinterpret_cast<const void *>(primary_kernel<true, true>); hipLaunchKernelGGL((primary_kernel<true, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, start_row, argb_dev, rgba); }
-        else if(exact) { func = reinterpret_cast<const void *>(primary_kernel<true, false>); hipLaunchKernelGGL((primary_kernel<true, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, start_row, argb_dev, rgba); }
-        else if(vec4) { func = reinterpret_cast<const void *>(primary_kernel<false, true>); hipLaunchKernelGGL((primary_kernel<false, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, start_row, argb_dev, rgba); }
-        else { func = reinterpret_cast<const void *>(primary_kernel<false, false>); hipLaunchKernelGGL((primary_kernel<false, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, start_row, argb_dev, rgba); }
+        if(exact && vec4) { func = reinterpret_cast<const void *>(primary_kernel<true, true>); hipLaunchKernelGGL((primary_kernel<true, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba); }
+        else if(exact) { func = reinterpret_cast<const void *>(primary_kernel<true, false>); hipLaunchKernelGGL((primary_kernel<true, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba); }
+        else if(vec4) { func = reinterpret_cast<const void *>(primary_kernel<false, true>); hipLaunchKernelGGL((primary_kernel<false, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba); }
+        else { func = reinterpret_cast<const void *>(primary_kernel<false, false>); hipLaunchKernelGGL((primary_kernel<false, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba); }
     } else if(b->all_terminal && vc.n_spheres <= static_cast<uint32_t>(kLdsSpheres)) {
         // waves per strip: as many as divide the pixel's sample blocks evenly (or nearly so)
         const uint32_t nblocks = (vc.spp + AEHIP_SAMPLE_BLOCK - 1u) / AEHIP_SAMPLE_BLOCK;
@@ -2528,16 +2594,15 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         const bool tiled = one && !exact && static_cast<uint64_t>(vc.width) * vc.row_count >= (1ull << 22);
         const uint32_t rows_per_group = tiled ? static_cast<uint32_t>(kTileH) : static_cast<uint32_t>(kTileH) >> split_log2;
         const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + rows_per_group - 1) / rows_per_group);
-        // the row of workgroups the launch starts with: the one nearest the sphere's centre on the
-        // image in the fast build (measured 0.489 -> 0.478 ms a 4K frame; the exact build, whose
-        // background rows are not that much shorter than its others, measured no gain and keeps row 0)
-        const uint32_t start_group = one && !exact ? sphere_centre_row(b, vc) / rows_per_group : 0u;
-        const uint32_t split_arg = split_log2 | (tiled ? kCameraTiled : 0u) | (start_group << 16);
+        // the rows of workgroups in which the sphere can be hit, for the fast build's order of rows
+        // (edges_first_row; the exact build, whose strips cost much the same wherever they are, keeps plain order)
+        const uint32_t row_order = one && !exact && grid.y <= 0xffffu ? sphere_group_rows(b, vc, rows_per_group, grid.y) : 1u;
+        const uint32_t split_arg = split_log2 | (tiled ? kCameraTiled : 0u);
         const bool fold = (vc.flags & kFlagFoldScreen) != 0;
 #define AEHIP_LAUNCH_CAMERA(E, O, F, A)                                                                                \
     do {                                                                                                               \
         func = reinterpret_cast<const void *>(camera_kernel<E, O, F, A>);                                              \
-        hipLaunchKernelGGL((camera_kernel<E, O, F, A>), grid, dim3(kBlock), 0, stream, vc, b->cc, split_arg,           \
+        hipLaunchKernelGGL((camera_kernel<E, O, F, A>), grid, dim3(kBlock), 0, stream, vc, b->cc, split_arg, row_order, \
                            b->d_geom, b->d_sample_terms, argb_dev, rgba, (E) && (O) && (F) && !(vc.flags & AEHIP_FLAG_WALK_ALL) ? b->d_row_miss : nullptr); \
     } while(0)
         // one ray per sample, whether the sample loop walks it or the pixel's bounds decide it; a
@@ -2562,9 +2627,9 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
                 const uint32_t per_group = 64u * (static_cast<uint32_t>(kBlock / 64) >> split_log2);
                 const uint32_t list_groups = (last - first + per_group - 1u) / per_group;
                 const dim3 line(list_groups + grid.x * grid.y);
-                if(fold && axial) { func = reinterpret_cast<const void *>(camera_hybrid_kernel<true, true>); hipLaunchKernelGGL((camera_hybrid_kernel<true, true>), line, dim3(kBlock), 0, stream, vc, b->cc, split_arg, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, grid.x); }
-                else if(fold) { func = reinterpret_cast<const void *>(camera_hybrid_kernel<true, false>); hipLaunchKernelGGL((camera_hybrid_kernel<true, false>), line, dim3(kBlock), 0, stream, vc, b->cc, split_arg, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, grid.x); }
-                else { func = reinterpret_cast<const void *>(camera_hybrid_kernel<false, false>); hipLaunchKernelGGL((camera_hybrid_kernel<false, false>), line, dim3(kBlock), 0, stream, vc, b->cc, split_arg, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, grid.x); }
+                if(fold && axial) { func = reinterpret_cast<const void *>(camera_hybrid_kernel<true, true>); hipLaunchKernelGGL((camera_hybrid_kernel<true, true>), line, dim3(kBlock), 0, stream, vc, b->cc, split_arg, row_order, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, grid.x); }
+                else if(fold) { func = reinterpret_cast<const void *>(camera_hybrid_kernel<true, false>); hipLaunchKernelGGL((camera_hybrid_kernel<true, false>), line, dim3(kBlock), 0, stream, vc, b->cc, split_arg, row_order, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, grid.x); }
+                else { func = reinterpret_cast<const void *>(camera_hybrid_kernel<false, false>); hipLaunchKernelGGL((camera_hybrid_kernel<false, false>), line, dim3(kBlock), 0, stream, vc, b->cc, split_arg, row_order, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, grid.x); }
             }
             else if(one && axial) AEHIP_LAUNCH_CAMERA(false, true, false, true);
             else if(one) AEHIP_LAUNCH_CAMERA(false, true, false, false);
@@ -3247,6 +3312,17 @@ int load_rccl(rccl_api &api) {
 
 // Band i of n when the frame's rows are cut into tiles of tile_rows rows dealt round-robin: which
 // rows it has and where its rows start among the densely stored bands (band order).
+#ifdef AEHIP_WAVE_TIMELINE
+// out: 3 words a wave (start, end in 10 ns ticks; 1 = rendered listed pixels), at most `capacity` waves; returns the count
+extern "C" int aehip_wave_timeline(unsigned long long *out, unsigned int capacity) {
+    unsigned int n = 0;
+    if(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_timeline_waves), sizeof(n)) != hipSuccess) return -1;
+    n = std::min(std::min(n, capacity), kTimelineWaves);
+    if(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 3u * n) != hipSuccess) return -1;
+    return static_cast<int>(n);
+}
+#endif
+
 extern "C" int aehip_frame_band(uint32_t row_count, uint32_t tile_rows, int n_bands, int band, uint32_t *first_row,
                                 uint32_t *rows, uint32_t *rows_before) {
     if(n_bands < 1 || band < 0 || band >= n_bands || !first_row || !rows || !rows_before) return fail(AEHIP_E_INVALID, "aehip_frame_band: bad argument");

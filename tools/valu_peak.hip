@@ -44,6 +44,8 @@
 #define I_ADD(a, b, c) "v_add_f32 v" #a ", v" #a ", v" #c "\n"
 #define I_ADD_S(a, b, c) "v_add_f32 v" #a ", s22, v" #a "\n"
 #define I_PKFMA(a, b, c) "v_pk_fma_f32 v[" #a ":" #a "+1], v[" #a ":" #a "+1], v[" #b ":" #b "+1], v[" #c ":" #c "+1]\n"
+/* packed FMA with a scalar-register pair as one source (both halves read the pair's low word): two scalar-operand FMAs an instruction */
+#define I_PKFMA_S(a, b, c) "v_pk_fma_f32 v[" #a ":" #a "+1], v[" #a ":" #a "+1], s[22:23], v[" #c ":" #c "+1] op_sel_hi:[1,0,1]\n"
 #define I_MULLO(a, b, c) "v_mul_lo_u32 v" #a ", v" #a ", v" #b "\n"
 #define I_ADDU(a, b, c) "v_add_u32 v" #a ", v" #a ", v" #b "\n"
 #define I_ADDU_S(a, b, c) "v_add_u32 v" #a ", s22, v" #a "\n"
@@ -177,10 +179,10 @@ struct stamp {
         t0 = __builtin_amdgcn_s_memtime();                                                                             \
         r0 = __builtin_amdgcn_s_memrealtime();                                                                         \
         asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(t0), "s"(r0));                                                      \
-        asm volatile("s_mov_b32 s20, %0\n s_mov_b32 s22, %1\n"                                                         \
+        asm volatile("s_mov_b32 s20, %0\n s_mov_b32 s22, %1\n s_mov_b32 s23, %1\n"                                                       \
                      "1:\n" BODY64 "s_sub_u32 s20, s20, 1\n s_cmp_lg_u32 s20, 0\n s_cbranch_scc1 1b\n"                 \
                      :: "s"(iters), "s"(operand)                                                                       \
-                     : "s20", "s22", "scc", "vcc", "v0", "v3", "v6", "v7", "v8", "v9", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", \
+                     : "s20", "s22", "s23", "scc", "vcc", "v0", "v3", "v6", "v7", "v8", "v9", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", \
                        "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43",      \
                        "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",      \
                        "v60", "v61", "v62", "v63");                                                                    \
@@ -198,6 +200,7 @@ PROBE_KERNEL(k_mul, X4(ROT16(I_MUL)))
 PROBE_KERNEL(k_add, X4(ROT16(I_ADD)))
 PROBE_KERNEL(k_add_sgpr, X4(ROT16(I_ADD_S)))
 PROBE_KERNEL(k_pk_fma, X4(PAIR8(I_PKFMA)) X4(PAIR8(I_PKFMA)))
+PROBE_KERNEL(k_pk_fma_sgpr, X4(PAIR8(I_PKFMA_S)) X4(PAIR8(I_PKFMA_S)))
 PROBE_KERNEL(k_mul_lo_u32, X4(ROT16(I_MULLO)))
 PROBE_KERNEL(k_add_u32, X4(ROT16(I_ADDU)))
 PROBE_KERNEL(k_add_u32_sgpr, X4(ROT16(I_ADDU_S)))
@@ -331,6 +334,7 @@ int main(int argc, char **argv) {
     run("add", k_add, 64, 1, cus, hz, d_out);
     run("add_sgpr_operand", k_add_sgpr, 64, 1, cus, hz, d_out);
     run("pk_fma", k_pk_fma, 64, 4, cus, hz, d_out);
+    run("pk_fma_sgpr_operand", k_pk_fma_sgpr, 64, 4, cus, hz, d_out);
     run("mul_lo_u32", k_mul_lo_u32, 64, 0, cus, hz, d_out);
     run("add_u32", k_add_u32, 64, 0, cus, hz, d_out);
     run("add_u32_sgpr_op", k_add_u32_sgpr, 64, 0, cus, hz, d_out);
