@@ -539,10 +539,58 @@ __device__ __forceinline__ void resolve_sphere(const float4 g, int index, float 
 // in the fast build, the value have the same bits as screen_sphere's (same operations in the same
 // order, on the host for the tabulated part); the exact build's u is rounded once more, far
 // inside the margin.  Spheres that pass are resolved from the sphere list as ever.
-__device__ __forceinline__ float screen_camera_entry(const float4 e, const f3 d, float &h_out) {
-    const float h = __builtin_fmaf(d.z, e.z, __builtin_fmaf(d.y, e.y, d.x * e.x));
-    h_out = h;
-    return __builtin_fmaf(h, h, e.w);
+//
+// The table of camera entries is stored four spheres at a time with the fields of two spheres side
+// by side -- x0 x1 y0 y1 z0 z1 u0 u1 | x2 x3 y2 y3 z2 z3 u2 u3 -- and padded to whole groups with
+// entries no ray can pass (u = -FLT_MAX).  A pair of fields is one 64-bit scalar operand of a packed
+// instruction: v_pk_fma_f32 with a scalar-register pair as a source issues at the packed rate (4.25
+// clocks for two lanes' worth, tools/valu_peak.hip), where v_fma_f32 with a scalar-register source
+// issues at half rate (4.2 clocks for one).  The same operations on the same numbers as one
+// sphere at a time would take, so the same bits, at half the issue slots: 8 packed instructions for
+// four spheres instead of 16 half-rate ones (10,000 spheres, primary rays: 4.6 -> 3.9 ms).  The same
+// packing of screen_sphere's ten operations for rays from anywhere measured no gain (10,000
+// spheres, depth 4: 34.8 -> 33.9 ms fast, 38.9 -> 40.0 ms exact) and is not used.
+typedef float float_pair __attribute__((ext_vector_type(2)));
+struct camera_group {
+    float_pair x01, y01, z01, u01, x23, y23, z23, u23;
+};
+__device__ __forceinline__ camera_group load_camera_group(const float4 *__restrict__ table, uint32_t group) {
+    const float_pair *p = reinterpret_cast<const float_pair *>(table + group * 4u);
+    return camera_group{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]};
+}
+template <bool EXACT>
+__device__ __forceinline__ void test_camera_group(const camera_group &cg, const float4 *__restrict__ spheres, int index, const f3 o,
+                                                  const f3 d, float a2, float a4, float &closest, int &hit) {
+    const float_pair dx = {d.x, d.x}, dy = {d.y, d.y}, dz = {d.z, d.z};
+    const float_pair h01 = __builtin_elementwise_fma(dz, cg.z01, __builtin_elementwise_fma(dy, cg.y01, dx * cg.x01));
+    const float_pair h23 = __builtin_elementwise_fma(dz, cg.z23, __builtin_elementwise_fma(dy, cg.y23, dx * cg.x23));
+    const float_pair k01 = __builtin_elementwise_fma(h01, h01, cg.u01);
+    const float_pair k23 = __builtin_elementwise_fma(h23, h23, cg.u23);
+    if(__builtin_fmaxf(__builtin_fmaxf(k01.x, k01.y), __builtin_fmaxf(k23.x, k23.y)) >= 0.0f) {
+        // the spheres themselves are only fetched for the few that pass (exact build; the fast
+        // build's roots come from the screening value and h alone)
+        if(k01.x >= 0.0f) resolve_sphere<EXACT>(spheres[index], index, k01.x, h01.x, o, d, a2, a4, closest, hit);
+        if(k01.y >= 0.0f) resolve_sphere<EXACT>(spheres[index + 1], index + 1, k01.y, h01.y, o, d, a2, a4, closest, hit);
+        if(k23.x >= 0.0f) resolve_sphere<EXACT>(spheres[index + 2], index + 2, k23.x, h23.x, o, d, a2, a4, closest, hit);
+        if(k23.y >= 0.0f) resolve_sphere<EXACT>(spheres[index + 3], index + 3, k23.y, h23.y, o, d, a2, a4, closest, hit);
+    }
+}
+// The walk of intersect_chunk (below) over the packed table; `count` spheres, the table padded to groups of four.
+template <bool EXACT>
+__device__ __forceinline__ void intersect_camera_table(const float4 *__restrict__ table, uint32_t count, const f3 o, const f3 d,
+                                                       float a2, float a4, float &closest, int &hit, const float4 *__restrict__ spheres) {
+    const uint32_t groups = (count + 3u) / 4u;
+    if(groups == 0u) return;
+    uint32_t g = 0;
+    camera_group A = load_camera_group(table, 0);
+    while(g + 2 <= groups) {
+        const camera_group B = load_camera_group(table, g + 1);
+        test_camera_group<EXACT>(A, spheres, static_cast<int>(g * 4u), o, d, a2, a4, closest, hit);
+        A = load_camera_group(table, min(g + 2, groups - 1));      // clamped: the last fetch may repeat a group
+        test_camera_group<EXACT>(B, spheres, static_cast<int>((g + 1) * 4u), o, d, a2, a4, closest, hit);
+        g += 2;
+    }
+    if(g < groups) test_camera_group<EXACT>(A, spheres, static_cast<int>(g * 4u), o, d, a2, a4, closest, hit);
 }
 
 struct sphere_group {
@@ -554,66 +602,50 @@ __device__ __forceinline__ sphere_group load_group(const float4 *__restrict__ li
     return sphere_group{p[0], p[1], p[2], p[3]};
 }
 
-// CAMERA: `sg` holds camera entries and `spheres` is the sphere list they were tabulated from.
-template <bool EXACT, bool CAMERA>
-__device__ __forceinline__ void test_group(const sphere_group &sg, const float4 *__restrict__ spheres, int index, const f3 o,
-                                           const f3 d, float a2, float a4, float &closest, int &hit) {
+template <bool EXACT>
+__device__ __forceinline__ void test_group(const sphere_group &sg, int index, const f3 o, const f3 d, float a2, float a4, float &closest,
+                                           int &hit) {
     float h0, h1, h2, h3;
-    const float k0 = CAMERA ? screen_camera_entry(sg.g0, d, h0) : screen_sphere<EXACT>(sg.g0, o, d, h0);
-    const float k1 = CAMERA ? screen_camera_entry(sg.g1, d, h1) : screen_sphere<EXACT>(sg.g1, o, d, h1);
-    const float k2 = CAMERA ? screen_camera_entry(sg.g2, d, h2) : screen_sphere<EXACT>(sg.g2, o, d, h2);
-    const float k3 = CAMERA ? screen_camera_entry(sg.g3, d, h3) : screen_sphere<EXACT>(sg.g3, o, d, h3);
+    const float k0 = screen_sphere<EXACT>(sg.g0, o, d, h0);
+    const float k1 = screen_sphere<EXACT>(sg.g1, o, d, h1);
+    const float k2 = screen_sphere<EXACT>(sg.g2, o, d, h2);
+    const float k3 = screen_sphere<EXACT>(sg.g3, o, d, h3);
     if(__builtin_fmaxf(__builtin_fmaxf(k0, k1), __builtin_fmaxf(k2, k3)) >= 0.0f) {
-        if constexpr(CAMERA) {
-            // the spheres themselves are only fetched for the few that pass (exact build; the fast
-            // build's roots come from the screening value and h alone)
-            if(k0 >= 0.0f) resolve_sphere<EXACT>(spheres[index], index, k0, h0, o, d, a2, a4, closest, hit);
-            if(k1 >= 0.0f) resolve_sphere<EXACT>(spheres[index + 1], index + 1, k1, h1, o, d, a2, a4, closest, hit);
-            if(k2 >= 0.0f) resolve_sphere<EXACT>(spheres[index + 2], index + 2, k2, h2, o, d, a2, a4, closest, hit);
-            if(k3 >= 0.0f) resolve_sphere<EXACT>(spheres[index + 3], index + 3, k3, h3, o, d, a2, a4, closest, hit);
-        } else {
-            resolve_sphere<EXACT>(sg.g0, index, k0, h0, o, d, a2, a4, closest, hit);
-            resolve_sphere<EXACT>(sg.g1, index + 1, k1, h1, o, d, a2, a4, closest, hit);
-            resolve_sphere<EXACT>(sg.g2, index + 2, k2, h2, o, d, a2, a4, closest, hit);
-            resolve_sphere<EXACT>(sg.g3, index + 3, k3, h3, o, d, a2, a4, closest, hit);
-        }
+        resolve_sphere<EXACT>(sg.g0, index, k0, h0, o, d, a2, a4, closest, hit);
+        resolve_sphere<EXACT>(sg.g1, index + 1, k1, h1, o, d, a2, a4, closest, hit);
+        resolve_sphere<EXACT>(sg.g2, index + 2, k2, h2, o, d, a2, a4, closest, hit);
+        resolve_sphere<EXACT>(sg.g3, index + 3, k3, h3, o, d, a2, a4, closest, hit);
     }
 }
 
 // `list` is either the LDS chunk or (scalar mode) the list in global memory read with a
 // wave-uniform index.  Groups are fetched one ahead of the group being tested, alternating two
 // register sets so no copies are needed: the fetch of group g+1 is in flight while group g is
-// screened.  CAMERA: `list` is the table of camera entries and `spheres` the sphere list.
-template <bool EXACT, bool CAMERA = false>
+// screened.
+template <bool EXACT>
 __device__ __forceinline__ void intersect_chunk(const float4 *__restrict__ list, uint32_t count, uint32_t index_base,
-                                                const f3 o, const f3 d, float a2, float a4, float &closest, int &hit,
-                                                const float4 *__restrict__ spheres = nullptr) {
+                                                const f3 o, const f3 d, float a2, float a4, float &closest, int &hit) {
     const uint32_t groups = count / 4u;
     uint32_t g = 0;
     if(groups > 0) {
         sphere_group A = load_group(list, 0);
         while(g + 2 <= groups) {
             const sphere_group B = load_group(list, g + 1);
-            test_group<EXACT, CAMERA>(A, spheres, static_cast<int>(index_base + g * 4u), o, d, a2, a4, closest, hit);
+            test_group<EXACT>(A, static_cast<int>(index_base + g * 4u), o, d, a2, a4, closest, hit);
             A = load_group(list, min(g + 2, groups - 1));      // clamped: the last fetch may repeat a group
-            test_group<EXACT, CAMERA>(B, spheres, static_cast<int>(index_base + (g + 1) * 4u), o, d, a2, a4, closest, hit);
+            test_group<EXACT>(B, static_cast<int>(index_base + (g + 1) * 4u), o, d, a2, a4, closest, hit);
             g += 2;
         }
         if(g < groups) {
-            test_group<EXACT, CAMERA>(A, spheres, static_cast<int>(index_base + g * 4u), o, d, a2, a4, closest, hit);
+            test_group<EXACT>(A, static_cast<int>(index_base + g * 4u), o, d, a2, a4, closest, hit);
             g++;
         }
     }
     for(uint32_t i = g * 4u; i < count; i++) {
         const float4 s = list[i];
         float h;
-        if constexpr(CAMERA) {
-            const float k = screen_camera_entry(s, d, h);
-            if(k >= 0.0f) resolve_sphere<EXACT>(spheres[index_base + i], static_cast<int>(index_base + i), k, h, o, d, a2, a4, closest, hit);
-        } else {
-            const float k = screen_sphere<EXACT>(s, o, d, h);
-            resolve_sphere<EXACT>(s, static_cast<int>(index_base + i), k, h, o, d, a2, a4, closest, hit);
-        }
+        const float k = screen_sphere<EXACT>(s, o, d, h);
+        resolve_sphere<EXACT>(s, static_cast<int>(index_base + i), k, h, o, d, a2, a4, closest, hit);
     }
 }
 
@@ -669,7 +701,7 @@ __device__ __forceinline__ void intersect_prefiltered(const view_consts &vc, con
         const float v0 = prefilter_entry(e.g0, ray), v1 = prefilter_entry(e.g1, ray);
         const float v2 = prefilter_entry(e.g2, ray), v3 = prefilter_entry(e.g3, ray);
         if(__builtin_fmaxf(__builtin_fmaxf(v0, v1), __builtin_fmaxf(v2, v3)) >= 0.0f)
-            test_group<EXACT, false>(load_group(spheres, group), nullptr, static_cast<int>(group * 4u), o, d, a2, a4, closest, hit);
+            test_group<EXACT>(load_group(spheres, group), static_cast<int>(group * 4u), o, d, a2, a4, closest, hit);
     };
     const uint32_t groups = count / 4u;
     uint32_t g = 0;
@@ -858,7 +890,7 @@ __global__ __launch_bounds__(kBlock) void path_kernel(view_consts vc, const floa
             // a wave whose rays all start at the camera (every wave of a one-segment render, the
             // first iteration otherwise) walks the table of camera entries instead
             if(!__any(tracing && ps.bounce != 0)) {
-                if(tracing) intersect_chunk<EXACT, true>(camera_list, vc.n_spheres, 0, ps.o, ps.d, a2, a4, closest, hit, geom);
+                if(tracing) intersect_camera_table<EXACT>(camera_list, vc.n_spheres, ps.o, ps.d, a2, a4, closest, hit, geom);
             } else {
                 if(tracing) intersect_chunk<EXACT>(geom, vc.n_spheres, 0, ps.o, ps.d, a2, a4, closest, hit);
             }
@@ -1024,7 +1056,7 @@ __global__ __launch_bounds__(kBlock) void first_hit_kernel(view_consts vc, const
         }
         float closest = 3.402823466e+38f;
         int hit = -1;
-        intersect_chunk<EXACT, true>(camera_list, vc.n_spheres, 0, ps.o, ps.d, a2, a4, closest, hit, geom);
+        intersect_camera_table<EXACT>(camera_list, vc.n_spheres, ps.o, ps.d, a2, a4, closest, hit, geom);
         if(valid) radiance[(static_cast<size_t>(wstrip) * win.stride + local) * 64u + lane] = radiance3{closest, __int_as_float(hit), 0.0f};
     }
     if((vc.flags & AEHIP_FLAG_COUNT_RAYS) && lane == 0) atomicAdd(ray_counter + 1, 64ull * count);
@@ -1032,7 +1064,7 @@ __global__ __launch_bounds__(kBlock) void first_hit_kernel(view_consts vc, const
 
 template <bool EXACT, bool PREFILTER>
 __global__ __launch_bounds__(kBlock) void path_stream_kernel(view_consts vc, const float4 *__restrict__ geom,
-                                                             const float4 *__restrict__ prefilter_list,
+                                                                    const float4 *__restrict__ prefilter_list,
                                                              const float4 *__restrict__ matl,
                                                              const uint32_t *__restrict__ kind,
                                                              const uint32_t *__restrict__ sample_terms,
@@ -1165,7 +1197,7 @@ __global__ __launch_bounds__(kBlock) void path_stream_kernel(view_consts vc, con
 // walk for every lane whose ray has no hit yet.
 template <bool EXACT, bool PREFILTER>
 __global__ __launch_bounds__(kBlock) void path_stream_first_hits_kernel(view_consts vc, const float4 *__restrict__ geom,
-                                                                        const float4 *__restrict__ prefilter_list,
+                                                                                          const float4 *__restrict__ prefilter_list,
                                                              const float4 *__restrict__ matl,
                                                              const uint32_t *__restrict__ kind,
                                                              const uint32_t *__restrict__ sample_terms,
@@ -2412,7 +2444,7 @@ struct aehip_backend {
     camera_consts cc{};                      // sphere 0 relative to the camera (camera_kernel, ONE)
 
     float4 *d_geom = nullptr;                // n x (cx, cy, cz, r*r)
-    float4 *d_camera = nullptr;              // n x (oc.xyz, u): camera entries, see screen_camera_entry
+    float4 *d_camera = nullptr;              // camera entries (oc.xyz, u) of the spheres, packed four at a time: see load_camera_group
     float4 *d_prefilter = nullptr;           // n x (Cc.xyz, K'): prefilter entries, see prefilter_entry
     float last_trace_render_ms = 0.0f;       // render time of the last aehip_backend_trace of the current request
     bool prefilter_pays = false;             // few enough rays pass it for it to be worth its 8 operations a sphere
@@ -2915,10 +2947,10 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
         if(b->d_matl) (void)hipFree(b->d_matl);
         if(b->d_kind) (void)hipFree(b->d_kind);
         if(b->d_camera) (void)hipFree(b->d_camera);
-        if(b->d_prefilter) (void)hipFree(b->d_prefilter);
+            if(b->d_prefilter) (void)hipFree(b->d_prefilter);
         b->d_geom = nullptr; b->d_matl = nullptr; b->d_kind = nullptr; b->d_camera = nullptr; b->d_prefilter = nullptr; b->scene_capacity = 0;
         AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_geom), sizeof(float4) * n));
-        AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_camera), sizeof(float4) * n));
+        AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_camera), sizeof(float4) * ((n + 3u) / 4u * 4u)));      // whole groups of four
         AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_prefilter), sizeof(float4) * n));
         AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_matl), sizeof(float4) * n));
         AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_kind), sizeof(uint32_t) * n));
@@ -2928,7 +2960,8 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
         float4 *geom = static_cast<float4 *>(std::malloc(sizeof(float4) * n));
         float4 *matl = static_cast<float4 *>(std::malloc(sizeof(float4) * n));
         uint32_t *kind = static_cast<uint32_t *>(std::malloc(sizeof(uint32_t) * n));
-        float4 *camera = static_cast<float4 *>(std::malloc(sizeof(float4) * n));
+        const uint32_t n_padded = (n + 3u) / 4u * 4u;
+        float4 *camera = static_cast<float4 *>(std::malloc(sizeof(float4) * n_padded));
         float4 *prefilter = static_cast<float4 *>(std::malloc(sizeof(float4) * n));
         if(!geom || !matl || !kind || !camera || !prefilter) {
             std::free(geom); std::free(matl); std::free(kind); std::free(camera); std::free(prefilter);
@@ -3014,10 +3047,21 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
             b->cc.near_root_only = std::sqrt(static_cast<double>(occ)) - r0 > 1.001 * static_cast<double>(kTMin) ? 1u : 0u;
             b->cc.radius2 = geom[0].w;
         }
+        // the table of camera entries goes up in the packed layout of load_camera_group: whole
+        // groups of four (the padding can never pass: a screening value of about -1e30), the
+        // fields of two spheres side by side
+        for(uint32_t i = n; i < n_padded; i++) camera[i] = make_float4(0.0f, 0.0f, 0.0f, -1e30f);
+        for(uint32_t i = 0; i < n_padded; i += 4u) {
+            const float4 e0 = camera[i], e1 = camera[i + 1u], e2 = camera[i + 2u], e3 = camera[i + 3u];
+            camera[i] = make_float4(e0.x, e1.x, e0.y, e1.y);
+            camera[i + 1u] = make_float4(e0.z, e1.z, e0.w, e1.w);
+            camera[i + 2u] = make_float4(e2.x, e3.x, e2.y, e3.y);
+            camera[i + 3u] = make_float4(e2.z, e3.z, e2.w, e3.w);
+        }
         hipError_t e = hipMemcpyAsync(b->d_geom, geom, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
         if(e == hipSuccess) e = hipMemcpyAsync(b->d_matl, matl, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
         if(e == hipSuccess) e = hipMemcpyAsync(b->d_kind, kind, sizeof(uint32_t) * n, hipMemcpyHostToDevice, b->stream);
-        if(e == hipSuccess) e = hipMemcpyAsync(b->d_camera, camera, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
+        if(e == hipSuccess) e = hipMemcpyAsync(b->d_camera, camera, sizeof(float4) * n_padded, hipMemcpyHostToDevice, b->stream);
         if(e == hipSuccess) e = hipMemcpyAsync(b->d_prefilter, prefilter, sizeof(float4) * n, hipMemcpyHostToDevice, b->stream);
         if(e == hipSuccess) e = hipStreamSynchronize(b->stream);
         std::free(geom); std::free(matl); std::free(kind); std::free(camera); std::free(prefilter);
