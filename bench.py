@@ -17,8 +17,8 @@ run and reported under "exact".  --mode exact swaps the two.
 
 The line also carries
   roofline      the FP32 operations the kernel EXECUTES per launch (rocprofv3 counters
-                SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 of the same command, profiles/r02_counters.json:
-                64 x (ADD + MUL + 2 FMA + TRANS)) / its mean launch time (HIP events on the launch
+                SQ_INSTS_VALU_FLOPS_FP32 and SQ_INSTS_VALU_TRANS_F32 of the same command,
+                profiles/r02_counters.json: 64 x (FLOPS_FP32 + TRANS)) / its mean launch time (HIP events on the launch
                 stream, inside the timed region) against the FP32 vector peak -- a fraction that cannot
                 exceed 1; the flops of the reference's formulas for the same frame are reported beside
                 it as algorithmic_tflops / work_reduction,
@@ -353,7 +353,7 @@ def main():
                 if "WRITE_SIZE" in k and "FETCH_SIZE" in k:
                     # HBM bytes per launch: WRITE_SIZE in KiB; FETCH_SIZE in KiB, x2 on gfx950 (it under-reports wide reads)
                     r["traffic"] = int((k["WRITE_SIZE"] * 1024 + k["FETCH_SIZE"] * 2048) / world)
-                r["note"] = ("achieved = 64 x (ADD_F32 + MUL_F32 + 2 FMA_F32 + TRANS_F32) wave-instructions per launch (rocprofv3 "
+                r["note"] = ("achieved = 64 x (SQ_INSTS_VALU_FLOPS_FP32 + TRANS_F32) per launch (rocprofv3 "
                              "counters of this command, committed) / this run's launch time; algorithmic_tflops prices the flops of "
                              "the reference's formulas (36 per missing sample, 67 per hit) over the same time and may exceed the "
                              "peak: bounds over a pixel's sample positions decide the pixels whose samples all miss (78 % of this "

@@ -9,10 +9,14 @@ the per-FRAME totals of each counter (sum over the run's dispatches / frames ren
 number of dispatches per frame and the mean dispatch duration.  The file also records the sha256
 of the kernel sources it was measured on; bench.py refuses figures from another version.
 
-Executed FP32 flops of a kernel = 64 * (ADD_F32 + MUL_F32 + 2 * FMA_F32 + TRANS_F32): the SQ
-counters count wave-level instructions, every lane of a wave64 instruction counts whether or not
-its EXEC bit is set, so this is issue-slot work -- an upper bound of useful flops and exactly what
-the VALU roofline prices.
+Executed FP32 flops of a kernel = 64 * (FLOPS_FP32 + TRANS_F32).  SQ_INSTS_VALU_FLOPS_FP32 is the
+hardware's own flop weight of the wave-level FP32 instructions issued: 1 for an add or a multiply,
+2 for an FMA, and twice that for the packed forms (v_pk_fma_f32 counts once in FMA_F32 but works
+on two values a lane: measured on the camera table's walk, FLOPS_FP32 = 2 MUL_F32 + 4 FMA_F32
+there).  Where a profile has no FLOPS_FP32 the sum ADD_F32 + MUL_F32 + 2 FMA_F32 stands in, which
+is the same number for kernels without packed instructions.  Every lane of a wave64 instruction
+counts whether or not its EXEC bit is set, so this is issue-slot work -- an upper bound of useful
+flops and exactly what the VALU roofline prices.
 """
 import hashlib
 import json
@@ -66,7 +70,9 @@ def main():
                 k.setdefault("avg_dispatch_us", {})[sub] = dur / 1e3
     for k in kernels.values():
         k["full_names"] = [n[:160] for n in k["full_names"]]
-        if all(c in k for c in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32")):
+        if "SQ_INSTS_VALU_FLOPS_FP32" in k and "SQ_INSTS_VALU_TRANS_F32" in k:
+            k["executed_fp32_flop_per_frame"] = 64.0 * (k["SQ_INSTS_VALU_FLOPS_FP32"] + k["SQ_INSTS_VALU_TRANS_F32"])
+        elif all(c in k for c in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32")):
             k["executed_fp32_flop_per_frame"] = 64.0 * (k["SQ_INSTS_VALU_ADD_F32"] + k["SQ_INSTS_VALU_MUL_F32"]
                                                         + 2.0 * k["SQ_INSTS_VALU_FMA_F32"] + k["SQ_INSTS_VALU_TRANS_F32"])
     doc = {"workloads": {}}

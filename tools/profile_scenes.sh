@@ -17,7 +17,7 @@ for CASE in stress10k_1080p_2spp_d1 stress10k_1080p_4spp_d4 divergence_1080p_16s
     mkdir -p "$OUT/$CASE"
     timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY -d "$OUT/$CASE/pmc_sq" -o pmc -- python3 "$ROOT/tools/bench_scenes.py" --mode "$MODE" --reps $REPS --case $CASE \
         > "$OUT/$CASE/pmc_sq.log" 2>&1 || exit 2
-    timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT GRBM_GUI_ACTIVE -d "$OUT/$CASE/pmc_flops" -o pmc -- python3 "$ROOT/tools/bench_scenes.py" --mode "$MODE" --reps $REPS --case $CASE \
+    timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT GRBM_GUI_ACTIVE -d "$OUT/$CASE/pmc_flops" -o pmc -- python3 "$ROOT/tools/bench_scenes.py" --mode "$MODE" --reps $REPS --case $CASE \
         > "$OUT/$CASE/pmc_flops.log" 2>&1 || exit 3
     (cd "$ROOT" && python3 tools/collect_counters.py ${CASE}_$MODE $REPS "$OUT/$CASE" && python3 tools/summarize_profile.py "$OUT/$CASE" "$OUT/$CASE.txt" > /dev/null) || exit 4
     [ -n "$KEEP_DB" ] || rm -rf "$OUT/$CASE"

@@ -56,11 +56,10 @@ def main():
             if kname != last:
                 out.append(f"  {kname[:120]}")
                 last = kname
-            if cname in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_TRANS_F32"):
+            # the hardware's flop weight of the FP32 instructions issued (packed forms count twice), plus the transcendentals
+            if cname in ("SQ_INSTS_VALU_FLOPS_FP32", "SQ_INSTS_VALU_TRANS_F32"):
                 flops[kname] = flops.get(kname, 0.0) + 64.0 * val
                 flops[(kname, "us")] = dur / 1e3
-            if cname == "SQ_INSTS_VALU_FMA_F32":
-                flops[kname] = flops.get(kname, 0.0) + 128.0 * val
             extra = ""
             if cname == "FETCH_SIZE":
                 extra = f"  -> HBM read bytes/launch (x1024 x2 gfx950 correction) = {val * 1024 * 2:.3e}"
@@ -71,7 +70,7 @@ def main():
             if isinstance(kname, tuple):
                 continue
             us = flops[(kname, "us")]
-            out.append(f"  executed FP32 flop/launch = 64 x (ADD + MUL + 2 FMA + TRANS) = {total:.4e}  -> {total / (us * 1e-6) / 1e12:.2f} TFLOP/s "
+            out.append(f"  executed FP32 flop/launch = 64 x (FLOPS_FP32 + TRANS) = {total:.4e}  -> {total / (us * 1e-6) / 1e12:.2f} TFLOP/s "
                        f"= {total / (us * 1e-6) / 157.3e12:.3f} of the 157.3 TFLOP/s FP32 vector peak (this profiled run's {us:.1f} us)  [{kname[:60]}]")
         out.append("")
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
