@@ -357,7 +357,7 @@ def main():
                              "counters of this command, committed) / this run's launch time; algorithmic_tflops prices the flops of "
                              "the reference's formulas (36 per missing sample, 67 per hit) over the same time and may exceed the "
                              "peak: bounds over a pixel's sample positions decide the pixels whose samples all miss (78 % of this "
-                             "frame) without walking their samples, and the fast build's hits cost 9 instructions a sample")
+                             "frame) without walking their samples, and the fast build's hits cost 7 to 9 instructions a sample")
             else:
                 r["note"] = counters_error or "executed-operation counters exist for the default workload (1024 spp, depth 8) only"
             return r

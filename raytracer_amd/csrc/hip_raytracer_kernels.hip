@@ -1419,6 +1419,7 @@ struct pixel_class {
     bool faces_sphere;          // h = draw.oc > 0 at the pixel (h keeps its sign over a pixel whose samples all hit)
     bool newton_ok;             // the hit distance may be carried from cell to cell by one Newton step (kNewtonTolerance)
     bool newton_twice_ok;       // ... by two steps a cell
+    bool newton_flat_ok;        // ... by one step with 1 / sqrt(disc) constant along the row
 };
 
 // The fast build's hit loop carries the hit distance t of the unnormalised ray along a row of
@@ -1501,6 +1502,10 @@ __device__ __forceinline__ pixel_class classify_pixel(const view_consts &vc, con
     // a second step starts where the first ended (t_error carries a factor 2 to spare already)
     const float t_error_twice = 2.0f * (eps * t_error + t_error * t_error * dd_max / (2.0f * s_min));
     pc.newton_twice_ok = sane && t_error <= 0.25f * start && colour_per_t * t_error_twice <= kNewtonTolerance;
+    // with 1 / sqrt(disc) taken as constant along a row of cells (its value in the pixel's middle
+    // column): off by its relative change across the pixel on top of the expansion's own error
+    const float eps_flat = eps + cells * ds / s_min;
+    pc.newton_flat_ok = pc.newton_ok && colour_per_t * 2.0f * (eps_flat * start + start * start * dd_max / (2.0f * s_min)) <= kNewtonTolerance;
     return pc;
 }
 
@@ -1675,7 +1680,7 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
     // other waves get the classes through LDS.  Before that every wave tests the workgroup's whole
     // rectangle: around most of the frame nothing can be hit, and the workgroup ends without
     // classes or a barrier.
-    constexpr uint32_t kCulled = 1u, kSureHit = 2u, kListed = 4u, kNewton = 8u, kNewtonTwice = 16u;
+    constexpr uint32_t kCulled = 1u, kSureHit = 2u, kListed = 4u, kNewton = 8u, kNewtonTwice = 16u, kNewtonFlat = 32u;
     __shared__ uint32_t s_class[ONE ? kWaves : 1][64];
     __shared__ uint32_t s_strip_work[kWaves];
     uint32_t x = group_x * kTileW + (lane & 15u);
@@ -1689,7 +1694,7 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
         row = (packed >> 16) - list_row_bias;      // entries hold rows of the whole band; a launch may render part of it
     }
     const uint32_t y = image_row(vc, row);
-    bool culled = false, sure_hit = false, newton = false, newton_twice = false;
+    bool culled = false, sure_hit = false, newton = false, newton_twice = false, newton_flat = false;
     if constexpr(ONE) {
         if(pixel_list == nullptr && (!EXACT || row_miss != nullptr)) {
             const uint32_t grow0 = group_y * strips_per_group * 4u;
@@ -1707,7 +1712,8 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                 if(!pc.may_hit) cls |= kCulled;
                 if constexpr(!EXACT) {
                     if(cc.near_root_only != 0u && pc.may_hit && pc.well_conditioned)
-                        cls |= pc.faces_sphere ? (pc.newton_ok ? kNewton : pc.newton_twice_ok ? (kNewton | kNewtonTwice) : kSureHit) : kCulled;    // behind the camera: no root counts
+                        cls |= pc.faces_sphere ? (pc.newton_flat_ok ? (kNewton | kNewtonFlat) : pc.newton_ok ? kNewton : pc.newton_twice_ok ? (kNewton | kNewtonTwice) : kSureHit)
+                                               : kCulled;    // behind the camera: no root counts
                 }
                 if(vc.flags & AEHIP_FLAG_WALK_ALL) cls &= kListed;      // every pixel through the general loop
                 strip_work = __ballot(valid && (cls & (kCulled | kListed)) == 0u) != 0ull;
@@ -1732,6 +1738,7 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
             sure_hit = (cls & kSureHit) != 0u;
             newton = (cls & kNewton) != 0u;
             newton_twice = (cls & kNewtonTwice) != 0u;
+            newton_flat = (cls & kNewtonFlat) != 0u;
         }
     }
     const bool work = valid && !culled;
@@ -2033,7 +2040,8 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                         // T = t / 2 of the previous cell takes one Newton step on
                         //   f / 4 = dd T*T - h T + c / 4,   (f / 4)' = 2 dd T - h = -sqrt(disc) at the near root,
                         // with rho ~ 1 / sqrt(disc) from its first-order expansion about the pixel's centre
-                        // (one add a cell).  Nine full-rate vector instructions a sample; two rows
+                        // (one add a cell).  Nine full-rate vector instructions a sample, eight where h is a row's
+                        // constant and seven where rho is too (SIDEWAYS and FLAT below); two rows
                         // of equal length are walked side by side (they share u and u*u, and two
                         // independent chains keep the vector unit fed: measured 21 clocks a sample
                         // against 24 for one row at a time).
@@ -2049,21 +2057,26 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                             nr.h_row = __builtin_fmaf(nr.v, cc.oc[1], dz * cc.oc[2]);
                             nr.dd_row = __builtin_fmaf(nr.v, nr.v, dz2);
                             const float off_u = u_first - np.u_c, off_v = nr.v - np.v_c;
-                            nr.rho = __builtin_fmaf(np.rho_u, off_u - du, __builtin_fmaf(np.rho_v, off_v, np.rho_c));
+                            const float rho_column = __builtin_fmaf(np.rho_v, off_v, np.rho_c);        // in the pixel's middle column
+                            nr.rho = newton_flat ? rho_column : __builtin_fmaf(np.rho_u, off_u - du, rho_column);
                             nr.T = __builtin_fmaf(np.T_u, off_u, __builtin_fmaf(np.T_v, off_v, np.T_c));
                             return nr;
                         };
                         // (TWICE: some pixel of the strip needs a second step a cell -- newton_twice; the
                         // others keep their first step's value, so a pixel's arithmetic does not depend on its neighbours)
-                        auto walk_rows = [&](auto twice_tag) {
-                        constexpr bool TWICE = decltype(twice_tag)::value;
+                        // (SIDEWAYS: the sphere's centre is off the camera's axis horizontally, so h = draw.oc
+                        // changes along a row; in the reference's scene it does not and is the row's constant)
+                        // (FLAT: every pixel of the strip may take 1 / sqrt(disc) as constant along a row --
+                        // newton_flat; such a pixel among others steps by zero, the same arithmetic)
+                        auto walk_rows = [&](auto twice_tag, auto sideways_tag, auto flat_tag) {
+                        constexpr bool TWICE = decltype(twice_tag)::value, SIDEWAYS = decltype(sideways_tag)::value, FLAT = decltype(flat_tag)::value;
                         for(uint32_t s = s0; s < s1;) {
                             const cell_row cr = row_at(s, s1);
                             s += cr.count;
                             const float du = jitter ? vc.psx * cr.inv_cells : 0.0f;
                             const float u_first = __builtin_fmaf(jitter ? (cr.first + off.rx) * cr.inv_cells : 0.5f, vc.psx, ux0);
                             float u = u_first - du;
-                            const float drho = np.rho_u * du;
+                            const float drho = newton_flat ? 0.0f : np.rho_u * du;
                             newton_row ra = start_row(cr, u_first, du);
                             bool pair = false;
                             cell_row cr2 = cr;
@@ -2078,11 +2091,13 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
 #pragma unroll 2
                                 for(uint32_t k = 0; k < cr.count; k++) {
                                     u += du;
-                                    ra.rho += drho;
-                                    rb.rho += drho;
+                                    if constexpr(!FLAT) {
+                                        ra.rho += drho;
+                                        rb.rho += drho;
+                                    }
                                     const float uu = u * u;
                                     const float dd_a = uu + ra.dd_row, dd_b = uu + rb.dd_row;
-                                    const float h_a = __builtin_fmaf(u, oc_x_v, ra.h_row), h_b = __builtin_fmaf(u, oc_x_v, rb.h_row);
+                                    const float h_a = SIDEWAYS ? __builtin_fmaf(u, oc_x_v, ra.h_row) : ra.h_row, h_b = SIDEWAYS ? __builtin_fmaf(u, oc_x_v, rb.h_row) : rb.h_row;
                                     const float f4_a = __builtin_fmaf(ra.T, __builtin_fmaf(dd_a, ra.T, -h_a), c4_v);
                                     const float f4_b = __builtin_fmaf(rb.T, __builtin_fmaf(dd_b, rb.T, -h_b), c4_v);
                                     ra.T = __builtin_fmaf(f4_a, ra.rho, ra.T);
@@ -2106,9 +2121,9 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
 #pragma unroll 4
                                 for(uint32_t k = 0; k < cr.count; k++) {
                                     u += du;
-                                    ra.rho += drho;
+                                    if constexpr(!FLAT) ra.rho += drho;
                                     const float dd = __builtin_fmaf(u, u, ra.dd_row);
-                                    const float h = __builtin_fmaf(u, oc_x_v, ra.h_row);
+                                    const float h = SIDEWAYS ? __builtin_fmaf(u, oc_x_v, ra.h_row) : ra.h_row;
                                     const float f4 = __builtin_fmaf(ra.T, __builtin_fmaf(dd, ra.T, -h), c4_v);
                                     ra.T = __builtin_fmaf(f4, ra.rho, ra.T);
                                     if constexpr(TWICE) {
@@ -2125,8 +2140,18 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                             }
                         }
                         };
-                        if(__ballot(newton_twice) != 0ull) walk_rows(std::true_type{});
-                        else walk_rows(std::false_type{});
+                        const bool twice = __ballot(newton_twice) != 0ull, flat = __ballot(!newton_flat) == 0ull;
+                        const std::true_type yes{};
+                        const std::false_type no{};
+                        if(cc.oc[0] != 0.0f) {
+                            if(twice) walk_rows(yes, yes, no);
+                            else if(flat) walk_rows(no, yes, yes);
+                            else walk_rows(no, yes, no);
+                        } else {
+                            if(twice) walk_rows(yes, no, no);
+                            else if(flat) walk_rows(no, no, yes);
+                            else walk_rows(no, no, no);
+                        }
                     }
                     if(sure_hit) {
                         // The hit loop: every sample of the pixel hits at the near root (see the
@@ -2348,7 +2373,7 @@ __global__ __launch_bounds__(64) void row_miss_sums_kernel(view_consts vc, uint3
 // registers, one allocation step over what 8 waves leave each other, and the pass lives on its
 // occupancy -- measured 2.19 ms a frame at 7 waves against 2.06 at 8.)
 template <bool FOLD, bool AXIAL>
-__global__ __launch_bounds__(kBlock, 8) void camera_hybrid_kernel(view_consts vc, camera_consts cc, uint32_t split_log2, uint32_t row_order,
+__global__ __launch_bounds__(kBlock) void camera_hybrid_kernel(view_consts vc, camera_consts cc, uint32_t split_log2, uint32_t row_order,
                                                                const uint32_t *__restrict__ sample_terms,
                                                                uint32_t *__restrict__ argb, float4 *__restrict__ rgba,
                                                                const uint32_t *__restrict__ pixel_list, uint32_t list_count,
@@ -2618,12 +2643,12 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         }
         // a sphere of (nearly) no radius has no usable 1/r: it goes through the list variant
         const bool one = single_sphere_camera_pass(b);
-        // one sphere: a workgroup may own a 16x16 tile and render its strips in rounds (camera_body)
-        // (measured on the 4K 1024-sample frame: the fast build's whole frame 0.55 -> 0.52 ms and half of it
-        // 0.333 -> 0.318 ms with tiles, but an eighth 0.111 -> 0.137 ms -- four times fewer, four
-        // times longer waves leave a short launch's tail emptier -- and the exact build, whose
-        // waves are long as it is, loses 5 % on the whole frame and half as much again on an eighth)
-        const bool tiled = one && !exact && static_cast<uint64_t>(vc.width) * vc.row_count >= (1ull << 22);
+        // one sphere: a workgroup may cover a 16x16 tile, every wave a strip of its own (camera_body)
+        // (measured on the 4K 1024-sample frame, fast build: the whole frame 0.55 -> 0.49 ms and half of it,
+        // 4.1 M pixels, 0.316 -> 0.293 ms with tiles, a quarter 0.170 -> 0.174 ms, an eighth 0.101 -> 0.125 ms
+        // -- four times fewer, four times longer waves leave a short launch's tail emptier -- and the
+        // exact build, whose waves are long as it is, loses 7 % on the whole frame)
+        const bool tiled = one && !exact && static_cast<uint64_t>(vc.width) * vc.row_count >= 4000000ull;
         const uint32_t rows_per_group = tiled ? static_cast<uint32_t>(kTileH) : static_cast<uint32_t>(kTileH) >> split_log2;
         const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + rows_per_group - 1) / rows_per_group);
         // the rows of workgroups in which the sphere can be hit, for the fast build's order of rows
