@@ -130,8 +130,8 @@ HIT_FRACTION_16_9 = 1832112.0 / 8294400.0   # sphere pixels in the reference's o
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)        # a frame is ~2 ms: the first dozen run below the
-    ap.add_argument("--warmup", type=int, default=10)       # clocks the GPU settles at, so warm up that long
+    ap.add_argument("--steps", type=int, default=200)       # a frame is ~0.4 ms: the first few milliseconds run below
+    ap.add_argument("--warmup", type=int, default=50)       # the clocks the GPU settles at, so warm up that long
     ap.add_argument("--mode", choices=["fast", "exact"], default="fast")
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--depth", type=int, default=8)

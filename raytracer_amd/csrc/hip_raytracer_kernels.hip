@@ -1612,6 +1612,66 @@ constexpr uint32_t kCameraTiled = 0x100u;      // a workgroup owns a 16x16 tile 
 // a rectangle, 64 consecutive entries taking a strip's place, group_x counting the groups.
 // SKIP_LISTED: pixels that pixel_needs_reference() are left out (the same launch renders them
 // from the list with the exact build's arithmetic, see camera_hybrid_kernel).
+// a pixel's mean colour from the sum of its samples (alpha 1)
+__device__ __forceinline__ float4 mean_colour(const view_consts &vc, f3 total) {
+    const float n = static_cast<float>(vc.spp);
+    // the mean is a true division in both builds (once per pixel): an approximate reciprocal
+    // would turn a row of exact 1.0 samples into 0.99999994 and the truncating pack into 254
+    return make_float4(clamp01(total.x / n), clamp01(total.y / n), clamp01(total.z / n), 1.0f);
+}
+
+// fast build: the sum of a pixel all of whose samples miss -- the row background times the sample count
+__device__ __forceinline__ f3 background_total(const view_consts &vc, uint32_t py) {
+    const f3 bg_row = row_background<false>(vc, py);
+    const float misses = static_cast<float>(vc.spp);
+    return f3{misses * bg_row.x, misses * bg_row.y, misses * bg_row.z};
+}
+
+// Fast build, one sphere: the background outside the box of workgroups in which the sphere can be
+// hit (sphere_box, host side), written by the last workgroups of the launch instead of by one
+// workgroup a tile.  Fill workgroup f takes segment f % kFillSegments of row f / kFillSegments of
+// workgroups, less the box's columns where the row is one of the box's; a wave takes every
+// fourth image row of it and writes the row's one colour over the span, 16 bytes a lane where
+// the frame's width and address allow.  (A 4K frame's background: 100,000 waves of 64 pixels each,
+// 50 us of a launch bound by how fast waves start, against 540 workgroups that store at the
+// memory's rate.)
+constexpr uint32_t kFillSegments = 4;
+__device__ __forceinline__ void fill_background(const view_consts &vc, uint32_t f, uint32_t rows_per_group, uint32_t row_order,
+                                                uint32_t box_cols, uint32_t *__restrict__ argb, float4 *__restrict__ rgba) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, waves = blockDim.x >> 6;
+    const uint32_t r = f / kFillSegments, j = f - r * kFillSegments;
+    const uint32_t groups_x = (vc.width + kTileW - 1u) / kTileW;
+    const uint32_t segment = ((groups_x + kFillSegments - 1u) / kFillSegments) * kTileW;
+    const uint32_t x0 = min(j * segment, vc.width), x1 = min(x0 + segment, vc.width);
+    // [x0, left_end) and [right_begin, x1): the segment without the box's columns
+    uint32_t left_end = x1, right_begin = x1;
+    if(r >= (row_order & 0xffffu) && r <= (row_order >> 16)) {
+        const uint32_t c0 = (box_cols & 0xffffu) * kTileW, c1 = min(((box_cols & 0xffffu) + (box_cols >> 16)) * kTileW, vc.width);
+        left_end = min(x1, max(x0, c0));
+        right_begin = max(x0, min(x1, c1));
+    }
+    const bool wide = (vc.width & 3u) == 0u && (reinterpret_cast<uintptr_t>(argb) & 15u) == 0u;
+    for(uint32_t k = wave; k < rows_per_group; k += waves) {
+        const uint32_t row = r * rows_per_group + k;
+        if(row >= vc.row_count) break;
+        const float4 mean = mean_colour(vc, background_total(vc, image_row(vc, row)));
+        const uint32_t word = pack_argb32(mean.x, mean.y, mean.z);
+        const size_t base = static_cast<size_t>(row) * vc.width;
+        for(int side = 0; side < 2; side++) {
+            const uint32_t xa = side == 0 ? x0 : right_begin, xb = side == 0 ? left_end : x1;
+            if(wide) {      // (the spans begin and end at multiples of the tile width or at the frame's edge)
+                uint4 *line = reinterpret_cast<uint4 *>(argb + base);
+                for(uint32_t q = (xa >> 2) + lane; q < (xb >> 2); q += 64u) line[q] = make_uint4(word, word, word, word);
+            } else {
+                for(uint32_t x = xa + lane; x < xb; x += 64u) argb[base + x] = word;
+            }
+            if(rgba) {
+                for(uint32_t x = xa + lane; x < xb; x += 64u) rgba[base + x] = mean;
+            }
+        }
+    }
+}
+
 template <bool EXACT, bool ONE, bool FOLD, bool AXIAL, bool SKIP_LISTED, bool FAST_AFTER_DISC = false>
 __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_consts &cc, uint32_t split_and_tile,
                                             const float4 *__restrict__ geom, const uint32_t *__restrict__ sample_terms,
@@ -1645,15 +1705,10 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
     const uint32_t nblocks = (vc.spp + AEHIP_SAMPLE_BLOCK - 1u) / AEHIP_SAMPLE_BLOCK;
 
     auto store_pixel = [&](uint32_t px, uint32_t prow, f3 total) {
-        const float n = static_cast<float>(vc.spp);
-        // the mean is a true division in both builds (once per pixel): an approximate reciprocal
-        // would turn a row of exact 1.0 samples into 0.99999994 and the truncating pack into 254
-        const float r = clamp01(total.x / n);
-        const float g = clamp01(total.y / n);
-        const float b = clamp01(total.z / n);
+        const float4 mean = mean_colour(vc, total);
         const size_t idx = static_cast<size_t>(prow) * vc.width + px;
-        argb[idx] = pack_argb32(r, g, b);
-        if(rgba) rgba[idx] = make_float4(r, g, b, 1.0f);
+        argb[idx] = pack_argb32(mean.x, mean.y, mean.z);
+        if(rgba) rgba[idx] = mean;
     };
     // a pixel all of whose samples miss: the row background summed spp times -- in the fast build a
     // product, in the exact build the sum in sample order that set-up tabulated per image row
@@ -1662,9 +1717,7 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
             const float4 t = row_miss[py];
             return f3{t.x, t.y, t.z};
         } else {
-            const f3 bg_row = row_background<EXACT>(vc, py);
-            const float misses = static_cast<float>(vc.spp);
-            return f3{misses * bg_row.x, misses * bg_row.y, misses * bg_row.z};
+            return background_total(vc, py);
         }
     };
 
@@ -2369,27 +2422,35 @@ __global__ __launch_bounds__(64) void row_miss_sums_kernel(view_consts vc, uint3
 // discriminant (the reference's ray, normalisation and hit decision, bit for bit) and the fast
 // arithmetic after it, the others the rectangle in the fast arithmetic minus those pixels.  One launch, so the few hundred list workgroups run beside the bulk instead of
 // on an empty chip (as a launch of their own they took 0.3 ms of a 2.2 ms 4K frame).
-// (8 waves per SIMD asked for explicitly: the two bodies together would otherwise take 98 scalar
-// registers, one allocation step over what 8 waves leave each other, and the pass lives on its
-// occupancy -- measured 2.19 ms a frame at 7 waves against 2.06 at 8.)
+// (No occupancy bound: held to the 64 vector registers of eight waves a SIMD the rectangle's body
+// spilled eight of them and rebuilt constants inside its row loop; with the 78 it takes, six
+// waves, the 4K 1024-sample frame went from 0.433 to 0.408 ms.)
 template <bool FOLD, bool AXIAL>
 __global__ __launch_bounds__(kBlock) void camera_hybrid_kernel(view_consts vc, camera_consts cc, uint32_t split_log2, uint32_t row_order,
                                                                const uint32_t *__restrict__ sample_terms,
                                                                uint32_t *__restrict__ argb, float4 *__restrict__ rgba,
                                                                const uint32_t *__restrict__ pixel_list, uint32_t list_count,
-                                                               uint32_t list_row_bias, uint32_t list_groups, uint32_t groups_x) {
+                                                               uint32_t list_row_bias, uint32_t list_groups, uint32_t box_cols,
+                                                               uint32_t box_groups, uint32_t rows_per_group) {
 #ifdef AEHIP_WAVE_TIMELINE
-    timeline_stamp stamp{__builtin_amdgcn_s_memrealtime(), blockIdx.x < list_groups ? 1u : 0u};
+    timeline_stamp stamp{__builtin_amdgcn_s_memrealtime(), blockIdx.x < list_groups ? 1u : blockIdx.x - list_groups < box_groups ? 0u : 2u};
 #endif
     if(blockIdx.x < list_groups) {
         camera_body<true, true, FOLD, AXIAL, false, true>(vc, cc, split_log2, nullptr, sample_terms, argb, rgba, blockIdx.x, 0u, pixel_list,
                                                           list_count, list_row_bias, nullptr);
-    } else {
-        const uint32_t id = blockIdx.x - list_groups;
-        const uint32_t line = id / groups_x;
+        return;
+    }
+    // the box's workgroups (the whole grid when there is no box), rows in edges_first_row's order,
+    // then the workgroups that fill the background around the box
+    const uint32_t id = blockIdx.x - list_groups;
+    if(id < box_groups) {
+        const uint32_t width = box_cols >> 16;
+        const uint32_t line = id / width;
         const uint32_t gy = edges_first_row(line, row_order);
-        camera_body<false, true, false, AXIAL, true>(vc, cc, split_log2, nullptr, sample_terms, argb, rgba, id - line * groups_x, gy, nullptr, 0u, 0u,
-                                                     nullptr);
+        camera_body<false, true, false, AXIAL, true>(vc, cc, split_log2, nullptr, sample_terms, argb, rgba, (box_cols & 0xffffu) + (id - line * width),
+                                                     gy, nullptr, 0u, 0u, nullptr);
+    } else {
+        fill_background(vc, id - box_groups, rows_per_group, row_order, box_cols, argb, rgba);
     }
 }
 
@@ -2608,6 +2669,50 @@ uint32_t sphere_group_rows(const aehip_backend *b, const view_consts &vc, uint32
     return hi < lo ? 1u : lo | (hi << 16);
 }
 
+// The box of workgroups (rows_per_group band rows by kTileW columns each) outside of which
+// classify_pixel calls every pixel a miss: rows packed lo | hi << 16 like sphere_group_rows,
+// columns first | count << 16.  False when there is no such box.  A pixel may be hit (or be an
+// ill-conditioned one) only if at one of its corners disc >= -(1.01 kScreenMargin + 1e-5) big
+// less the discriminant's second-order terms over a pixel (classify_pixel), big = h*h +
+// dd*(oc.oc + r*r) at most its value there but for the pixel's width.  Both are quadratics in the
+// ray's (u, v); with twice that margin their sum is one, and where its form is negative definite
+// the region is an ellipse with the extent worked out here, two pixels added all round.
+bool sphere_box(const aehip_backend *b, const view_consts &vc, uint32_t rows_per_group, uint32_t groups_x, uint32_t groups_y,
+                uint32_t *rows, uint32_t *cols) {
+    const camera_consts &cc = b->cc;
+    const double ox = cc.oc[0], oy = cc.oc[1], oz = cc.oc[2], dz = 0.0 - static_cast<double>(vc.cam[2]);
+    const double m = 2.0 * (1.01 * static_cast<double>(kScreenMargin) + 1e-5), big = cc.magnitude, c = cc.c;
+    // h*h (1 + m) + dd (m big - c), h = u ox + v oy + dz oz, dd = u*u + v*v + dz*dz
+    const double hh = 1.0 + m, k = m * big - c;
+    const double quu = hh * ox * ox + k, qvv = hh * oy * oy + k, quv = 2.0 * hh * ox * oy;
+    const double qu = 2.0 * hh * ox * dz * oz, qv = 2.0 * hh * oy * dz * oz;
+    const double psx = vc.psx, psy = vc.psy;
+    const double q0 = hh * dz * oz * dz * oz + k * dz * dz + std::fabs(quu) * psx * psx + std::fabs(quv) * psx * psy + std::fabs(qvv) * psy * psy;
+    if(!(quu < 0.0) || !(qvv < 0.0)) return false;
+    const double a2 = quv * quv - 4.0 * quu * qvv;
+    if(!(a2 < 0.0)) return false;
+    // rows: the largest value along u is non-negative between two values of v; columns likewise
+    const double r1 = 2.0 * quv * qu - 4.0 * quu * qv, r0 = qu * qu - 4.0 * quu * q0;
+    const double c1 = 2.0 * quv * qv - 4.0 * qvv * qu, c0 = qv * qv - 4.0 * qvv * q0;
+    const double dr = r1 * r1 - 4.0 * a2 * r0, dc = c1 * c1 - 4.0 * a2 * c0;
+    if(!(dr > 0.0) || !(dc > 0.0)) return false;
+    const double v_lo = (-r1 + std::sqrt(dr)) / (2.0 * a2), v_hi = (-r1 - std::sqrt(dr)) / (2.0 * a2);         // a2 < 0: lo < hi
+    const double u_lo = (-c1 + std::sqrt(dc)) / (2.0 * a2), u_hi = (-c1 - std::sqrt(dc)) / (2.0 * a2);
+    const double y_lo = (v_lo + static_cast<double>(vc.vh_half) + static_cast<double>(vc.cam[1])) / psy - 2.0;
+    const double y_hi = (v_hi + static_cast<double>(vc.vh_half) + static_cast<double>(vc.cam[1])) / psy + 2.0;
+    const double x_lo = (u_lo + static_cast<double>(vc.vw_half) + static_cast<double>(vc.cam[0])) / psx - 2.0;
+    const double x_hi = (u_hi + static_cast<double>(vc.vw_half) + static_cast<double>(vc.cam[0])) / psx + 2.0;
+    if(!(y_lo <= y_hi) || !(x_lo <= x_hi) || !(x_hi >= 0.0) || !(x_lo < static_cast<double>(vc.width))) return false;
+    const uint32_t row_lo = band_row_near(vc, y_lo) / rows_per_group;
+    const uint32_t row_hi = std::min(band_row_near(vc, y_hi) / rows_per_group, groups_y - 1u);
+    const uint32_t col_lo = x_lo > 0.0 ? static_cast<uint32_t>(x_lo) / static_cast<uint32_t>(kTileW) : 0u;
+    const uint32_t col_hi = std::min(x_hi < 4.0e9 ? static_cast<uint32_t>(x_hi) / static_cast<uint32_t>(kTileW) : 0xffffffffu, groups_x - 1u);
+    if(row_hi < row_lo || col_hi < col_lo || row_hi > 0xffffu || col_hi > 0xffffu) return false;
+    *rows = row_lo | (row_hi << 16);
+    *cols = col_lo | ((col_hi - col_lo + 1u) << 16);
+    return true;
+}
+
 int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t stream, const stream_scratch &scratch) {
     const view_consts &vc = b->vc;
     // Launches of one backend share one scratch: a launch that uses it (the streamed pass, the ray
@@ -2683,10 +2788,18 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
                 const uint32_t first = b->ring_row_offset[row0], last = b->ring_row_offset[row0 + vc.row_count];
                 const uint32_t per_group = 64u * (static_cast<uint32_t>(kBlock / 64) >> split_log2);
                 const uint32_t list_groups = (last - first + per_group - 1u) / per_group;
-                const dim3 line(list_groups + grid.x * grid.y);
-                if(fold && axial) { func = reinterpret_cast<const void *>(camera_hybrid_kernel<true, true>); hipLaunchKernelGGL((camera_hybrid_kernel<true, true>), line, dim3(kBlock), 0, stream, vc, b->cc, split_arg, row_order, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, grid.x); }
-                else if(fold) { func = reinterpret_cast<const void *>(camera_hybrid_kernel<true, false>); hipLaunchKernelGGL((camera_hybrid_kernel<true, false>), line, dim3(kBlock), 0, stream, vc, b->cc, split_arg, row_order, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, grid.x); }
-                else { func = reinterpret_cast<const void *>(camera_hybrid_kernel<false, false>); hipLaunchKernelGGL((camera_hybrid_kernel<false, false>), line, dim3(kBlock), 0, stream, vc, b->cc, split_arg, row_order, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, grid.x); }
+                // where the sphere's box of workgroups is known, only its workgroups render tiles and
+                // fill_background's write the rest of the band (not when every sample is to be walked)
+                uint32_t box_rows = row_order, box_cols = grid.x << 16, box_groups = grid.x * grid.y, fill_groups = 0;
+                if(grid.x <= 0xffffu && grid.y <= 0xffffu && !(vc.flags & AEHIP_FLAG_WALK_ALL) &&
+                   sphere_box(b, vc, rows_per_group, grid.x, grid.y, &box_rows, &box_cols)) {
+                    box_groups = (box_cols >> 16) * ((box_rows >> 16) - (box_rows & 0xffffu) + 1u);
+                    fill_groups = grid.y * kFillSegments;
+                }
+                const dim3 line(list_groups + box_groups + fill_groups);
+                if(fold && axial) { func = reinterpret_cast<const void *>(camera_hybrid_kernel<true, true>); hipLaunchKernelGGL((camera_hybrid_kernel<true, true>), line, dim3(kBlock), 0, stream, vc, b->cc, split_arg, box_rows, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, box_cols, box_groups, rows_per_group); }
+                else if(fold) { func = reinterpret_cast<const void *>(camera_hybrid_kernel<true, false>); hipLaunchKernelGGL((camera_hybrid_kernel<true, false>), line, dim3(kBlock), 0, stream, vc, b->cc, split_arg, box_rows, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, box_cols, box_groups, rows_per_group); }
+                else { func = reinterpret_cast<const void *>(camera_hybrid_kernel<false, false>); hipLaunchKernelGGL((camera_hybrid_kernel<false, false>), line, dim3(kBlock), 0, stream, vc, b->cc, split_arg, box_rows, b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, box_cols, box_groups, rows_per_group); }
             }
             else if(one && axial) AEHIP_LAUNCH_CAMERA(false, true, false, true);
             else if(one) AEHIP_LAUNCH_CAMERA(false, true, false, false);
@@ -3382,7 +3495,7 @@ int load_rccl(rccl_api &api) {
 // Band i of n when the frame's rows are cut into tiles of tile_rows rows dealt round-robin: which
 // rows it has and where its rows start among the densely stored bands (band order).
 #ifdef AEHIP_WAVE_TIMELINE
-// out: 3 words a wave (start, end in 10 ns ticks; 1 = rendered listed pixels), at most `capacity` waves; returns the count
+// out: 3 words a wave (start, end in 10 ns ticks; 0 = rendered a tile, 1 = listed pixels, 2 = filled background), at most `capacity` waves; returns the count
 extern "C" int aehip_wave_timeline(unsigned long long *out, unsigned int capacity) {
     unsigned int n = 0;
     if(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_timeline_waves), sizeof(n)) != hipSuccess) return -1;

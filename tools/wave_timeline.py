@@ -2,7 +2,9 @@
 library (make timeline -> tools/bin/libhip_raytracer_timeline.so): how many waves are resident
 over the launch, how long the waves of each kind live, which waves end last.
 
-    make timeline && RAYTRACER_AMD_LIB=$PWD/tools/bin/libhip_raytracer_timeline.so python tools/wave_timeline.py [spp]
+    make timeline && RAYTRACER_AMD_LIB=$PWD/tools/bin/libhip_raytracer_timeline.so python tools/wave_timeline.py [spp [bands rank tile_rows]]
+
+With bands: the launch of one rank's band of the frame (tiles of tile_rows rows dealt round-robin).
 """
 import ctypes
 import os
@@ -20,7 +22,11 @@ if not hasattr(lib, "aehip_wave_timeline"):
 W, H = 3840, 2160
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 back = rt.HipRaytracer(None)
-assert back.setup(W, H, spp, 8, 1, rt.FLAG_JITTER | rt.FLAG_FAST, rt.PASS_PATH, 0, 0, None, 0), back.last_error()
+band = {}
+if len(sys.argv) > 4:
+    from raytracer_amd.sharding import tiled_band
+    band = tiled_band(H, int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
+assert back.setup(W, H, spp, 8, 1, rt.FLAG_JITTER | rt.FLAG_FAST, rt.PASS_PATH, spheres=None, **band), back.last_error()
 argb = torch.zeros((H, W), dtype=torch.int32, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
 for _ in range(4):
@@ -36,7 +42,7 @@ start, end, kind = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0, a[:, 2]      
 dur = end - start
 span = end.max()
 print(f"{n} waves, launch {span:.1f} us (the stamps themselves cost a few per cent)")
-for k, name in ((1, "listed pixels"), (0, "rectangle")):
+for k, name in ((1, "listed pixels"), (0, "rectangle"), (2, "background")):
     m = kind == k
     if m.any():
         d = dur[m]
@@ -48,5 +54,5 @@ for label, sel in (("all waves", np.ones(n, bool)), ("waves over 5 us", dur > 5.
     print(f"{label}, resident per 2 % of the launch: " + " ".join(f"{c:.0f}" for c in conc))
 print("life histogram (us) 0-2-5-20-40-60-80-100-120-150-200+:", np.histogram(dur, bins=[0, 2, 5, 20, 40, 60, 80, 100, 120, 150, 200, 1e9])[0])
 for i in np.argsort(-end)[:12]:
-    print(f"  ends {end[i]:.1f} us: started {start[i]:.1f}, workgroup {i // 4}, wave {i % 4}, {'listed pixels' if kind[i] else 'rectangle'}")
+    print(f"  ends {end[i]:.1f} us: started {start[i]:.1f}, workgroup {i // 4}, wave {i % 4}, {('rectangle', 'listed pixels', 'background')[kind[i]]}")
 back.close()
