@@ -239,6 +239,12 @@ __device__ __forceinline__ pixel_offset offset_of_pixel(uint32_t pix_term) {
 __device__ __forceinline__ uint32_t cells_in_row(const view_consts &vc, uint32_t row) {
     return min(1u << vc.row_bits, vc.spp - (row << vc.row_bits));
 }
+// Every block of AEHIP_SAMPLE_BLOCK samples is an even number of full rows of cells: the listed
+// pixels of the fast build's camera pass then take 32 lanes a pixel row, a wave's two halves
+// walking two rows of cells side by side (camera_body).
+__host__ __device__ __forceinline__ bool blocks_are_pairs_of_rows(const view_consts &vc) {
+    return (vc.flags & AEHIP_FLAG_JITTER) != 0 && vc.spp % AEHIP_SAMPLE_BLOCK == 0u && (2u << vc.row_bits) <= AEHIP_SAMPLE_BLOCK;
+}
 __device__ __forceinline__ void sample_offset(const view_consts &vc, uint32_t sample, uint32_t pix_term, float &jx, float &jy) {
     const uint32_t r = sample >> vc.row_bits, i = sample & ((1u << vc.row_bits) - 1u);
     const uint32_t n_r = cells_in_row(vc, r);
@@ -1739,8 +1745,15 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
     uint32_t x = group_x * kTileW + (lane & 15u);
     uint32_t row = (group_y * strips_per_group + strip) * 4u + (lane >> 4);
     bool valid = (x < vc.width) && (row < vc.row_count);
+    // Listed pixels, blocks of whole pairs of rows: a pixel has two lanes, 32 apart, which walk the
+    // two rows of a pair at the same time and add their sums -- half as many steps a wave, twice
+    // as many waves.  (The listed pixels' waves are the longest of the launch, 20,000 dependent
+    // instructions in the reference's arithmetic at 1024 samples; in an eighth of a 4K frame the
+    // other waves were done after 62 us and these after 84.)
+    const bool halves = FAST_AFTER_DISC && pixel_list != nullptr && blocks_are_pairs_of_rows(vc);
+    const uint32_t half = halves ? lane >> 5 : 0u;
     if(pixel_list) {
-        const uint32_t entry = (group_x * strips_per_group + strip) * 64u + lane;
+        const uint32_t entry = halves ? (group_x * strips_per_group + strip) * 32u + (lane & 31u) : (group_x * strips_per_group + strip) * 64u + lane;
         valid = entry < list_count;
         const uint32_t packed = valid ? pixel_list[entry] : 0u;
         x = packed & 0xffffu;
@@ -1853,7 +1866,7 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
     };
     // (the integers are the same in every lane; saying so keeps the sample loops' counters and
     // branches in the scalar unit wherever the loops sit)
-    auto row_at = [&](uint32_t s, uint32_t s_end) {
+    auto row_at = [&](uint32_t s, uint32_t s_end, uint32_t rows_down = 0u) {     // rows_down: this lane's row is that many below
         cell_row cr;
         if(!jitter) {           // every sample at the pixel centre: one "row" for the whole range
             cr.count = __builtin_amdgcn_readfirstlane(s_end - s);
@@ -1874,14 +1887,14 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
         // in the scalar unit, instead of a division)
         cr.inv_cells = (n_r & (n_r - 1u)) == 0u ? __uint_as_float((127u - static_cast<uint32_t>(__builtin_ctz(n_r))) << 23)
                                                 : __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(1.0f / static_cast<float>(n_r))));
-        cr.jy = (static_cast<float>(r << vc.row_bits) + off.ry * static_cast<float>(n_r)) * vc.inv_spp;
+        cr.jy = (static_cast<float>((r + rows_down) << vc.row_bits) + off.ry * static_cast<float>(n_r)) * vc.inv_spp;
         return cr;
     };
 
     f3 sum = {0.0f, 0.0f, 0.0f};
 
     auto write_pixel = [&]() {
-        if(valid && part == 0u) {
+        if(valid && part == 0u && half == 0u) {
             if constexpr(EXACT && ONE) {
                 if(culled) sum = all_miss_total(y);
             }
@@ -1897,8 +1910,8 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                 const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
                 const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
                 for(uint32_t s = s0; s < s1;) {
-                    const cell_row cr = row_at(s, s1);
-                    s += cr.count;
+                    const cell_row cr = row_at(s, s1, half);
+                    s += halves ? 2u * cr.count : cr.count;
                     // the row's part of the sample's ray exactly as the reference builds it
                     // (src/software_raytracer.cpp:218-221), and of the folded screening ray
                     const float py = yf + cr.jy;
@@ -2012,6 +2025,11 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                         block.z += L.z;
                     }
                 }
+            }
+            if(halves) {        // the pair's other row (the same sum in both lanes: a + b = b + a)
+                block.x += __shfl_xor(block.x, 32, 64);
+                block.y += __shfl_xor(block.y, 32, 64);
+                block.z += __shfl_xor(block.z, 32, 64);
             }
             if(split == 1u) {
                 sum.x += block.x;
@@ -2786,7 +2804,7 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
                 // grid, from the list, in the reference's arithmetic
                 const uint32_t row0 = vc.tile_rows == 0 ? vc.row_begin - b->params.row_begin : 0u;
                 const uint32_t first = b->ring_row_offset[row0], last = b->ring_row_offset[row0 + vc.row_count];
-                const uint32_t per_group = 64u * (static_cast<uint32_t>(kBlock / 64) >> split_log2);
+                const uint32_t per_group = (blocks_are_pairs_of_rows(vc) ? 32u : 64u) * (static_cast<uint32_t>(kBlock / 64) >> split_log2);
                 const uint32_t list_groups = (last - first + per_group - 1u) / per_group;
                 // where the sphere's box of workgroups is known, only its workgroups render tiles and
                 // fill_background's write the rest of the band (not when every sample is to be walked)
