@@ -2799,9 +2799,9 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
             else if(fold) AEHIP_LAUNCH_CAMERA(true, false, true, false);
             else AEHIP_LAUNCH_CAMERA(true, false, false, false);
         } else {
-            if(one && b->ring_count > 0) {
-                // the band has ill-conditioned pixels: those of this launch's rows come first in the
-                // grid, from the list, in the reference's arithmetic
+            if(one && !b->ring_row_offset.empty()) {
+                // the band's ill-conditioned pixels (if it has any), those of this launch's rows, come
+                // first in the grid, from the list, in the reference's arithmetic
                 const uint32_t row0 = vc.tile_rows == 0 ? vc.row_begin - b->params.row_begin : 0u;
                 const uint32_t first = b->ring_row_offset[row0], last = b->ring_row_offset[row0 + vc.row_count];
                 const uint32_t per_group = (blocks_are_pairs_of_rows(vc) ? 32u : 64u) * (static_cast<uint32_t>(kBlock / 64) >> split_log2);

@@ -405,6 +405,32 @@ def test_background_around_the_spheres_box_is_the_exact_builds(case):
     assert int(np.abs(channels(fast_argb) - channels(exact_argb)).max()) <= 1
 
 
+@pytest.mark.parametrize("seed", range(48))
+def test_random_single_sphere_views_small_frames_fast_build_within_1e5_of_exact(seed):
+    """Random single-sphere views on small frames, wilder than the fine-grid ones: spheres partly or
+    wholly off the frame, behind or around the camera, a few pixels or most of the frame wide, odd
+    frame sizes, bands, 16 samples (ragged blocks) or 64 (blocks of whole rows: the listed pixels'
+    paired rows).  Every pixel is written (alpha 1 over a zeroed buffer) and within 1e-5 of the
+    exact build."""
+    rng = np.random.default_rng(9100 + seed)
+    s = np.zeros(1, dtype=rt.SPHERE_DTYPE)
+    depth = float(rng.choice([-1.2, -2.0, -4.0, -12.0, -40.0, 0.5, 3.0]))
+    spread = abs(depth) * float(rng.choice([0.0, 0.5, 1.2, 2.5]))
+    s["center"][0] = (rng.uniform(-spread, spread), rng.uniform(-spread, spread) * 0.6, depth)
+    s["radius"] = float(rng.choice([0.05, 0.3, 1.0, 3.0]) * rng.uniform(0.7, 1.3))
+    s["material"] = rt.MAT_NORMAL
+    cam = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.3, 0.3)), float(rng.choice([1.0, 0.4, 2.5])))
+    w, h = [(384, 216), (401, 230), (258, 143), (640, 64)][seed % 4]
+    kw = dict(spheres=s, cam=cam, spp=int(rng.choice([16, 64])), max_depth=2, seed=seed, jitter=bool(seed % 5))
+    if seed % 3 == 0:
+        r0 = int(rng.integers(0, h - 8))
+        kw.update(row_begin=r0, row_count=int(rng.integers(1, h - r0 + 1)))
+    _, fast, _ = render_device(w, h, fast=True, **kw)
+    _, exact, _ = render_device(w, h, **kw)
+    assert float(fast[..., 3].min()) == 1.0
+    assert float(np.abs(fast[..., :3] - exact[..., :3]).max()) <= 1e-5
+
+
 def test_fast_default_scene_jittered_matches_exact_closely():
     _, fast_rgba, _ = render_device(256, 144, spp=64, max_depth=1, seed=1, jitter=True, fast=True)
     _, exact_rgba, _ = render_device(256, 144, spp=64, max_depth=1, seed=1, jitter=True)
