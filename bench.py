@@ -85,7 +85,7 @@ def executed_work(doc, key, seconds_per_frame, share=1.0):
     w = (doc or {}).get("workloads", {}).get(key)
     if not w:
         return None
-    flop = valu = slots = 0.0
+    flop = valu = slots = cycles = busy_us = 0.0
     kernels = []
     for name, k in w["kernels"].items():
         # kernels of the timed frame only: set-up's (the ring list, the row table) run once per backend
@@ -101,6 +101,12 @@ def executed_work(doc, key, seconds_per_frame, share=1.0):
         cvt = k.get("SQ_INSTS_VALU_CVT", 0.0)
         slots += (n - trans - cvt) * CYCLES_FULL_RATE + trans * CYCLES_QUARTER_RATE + cvt * CYCLES_HALF_RATE
         kernels.append(name)
+        # shader clock while the kernel ran: GRBM_GUI_ACTIVE (summed over the 8 XCDs) over the launch's duration
+        # in the same counter pass; launches under 0.2 ms are left out (the counter also runs between launches)
+        us = k.get("avg_dispatch_us", {}).get("pmc_flops", 0.0) * k.get("dispatches_per_frame", 1.0)
+        if k.get("GRBM_GUI_ACTIVE") and us >= 200.0:
+            cycles += k["GRBM_GUI_ACTIVE"] / 8.0
+            busy_us += us
     if flop <= 0.0:
         return None
     flop *= share
@@ -113,6 +119,14 @@ def executed_work(doc, key, seconds_per_frame, share=1.0):
         out["valu_lane_ops_per_s"] = lane_ops
         out["valu_issue_vs_measured_full_rate"] = lane_ops / VALU_FULL_RATE_MEASURED
         out["valu_issue_cycles_lower_bound_frac"] = slots / (SIMDS * SUSTAINED_CLOCK_HZ * seconds_per_frame)
+    if busy_us > 0.0:
+        # The chip does not hold 2.4 GHz under these kernels (2.1-2.35 GHz, lower the denser the FMAs): the
+        # datasheet peak scaled to the clock it did hold, and the issue bound at that clock
+        ghz = cycles / busy_us / 1e3
+        out["shader_clock_ghz"] = ghz
+        out["frac_of_fp32_peak_at_that_clock"] = out["tflops"] / (FP32_VECTOR_PEAK_TFLOPS * ghz / 2.4)
+        if valu > 0.0:
+            out["valu_issue_cycles_lower_bound_frac_at_that_clock"] = slots / (SIMDS * ghz * 1e9 * seconds_per_frame)
     return out
 
 
