@@ -339,6 +339,52 @@ constexpr float kScreenMargin = 3e-5f;
 constexpr float kExactBelowQ = 6e-5f;
 
 // ------------------------------------------------------------------------------------------
+// Rows of one colour around a box of workgroups.  Workgroup f of the fill takes segment
+// f % kFillSegments of row f / kFillSegments of workgroups (rows_per_group band rows each), less
+// the box's columns (first | count << 16, in tiles of kTileW pixels) where the row is one of the
+// box's (lo | hi << 16); a wave takes every waves-th image row of it and writes the row's one
+// colour over the span, 16 bytes a lane where the frame's width and address allow.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kFillSegments = 4;
+template <typename RowColour>
+__device__ __forceinline__ void fill_around_box(const view_consts &vc, uint32_t f, uint32_t rows_per_group, uint32_t box_rows,
+                                                uint32_t box_cols, uint32_t *__restrict__ argb, float4 *__restrict__ rgba,
+                                                RowColour row_colour) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, waves = blockDim.x >> 6;
+    const uint32_t r = f / kFillSegments, j = f - r * kFillSegments;
+    const uint32_t groups_x = (vc.width + kTileW - 1u) / kTileW;
+    const uint32_t segment = ((groups_x + kFillSegments - 1u) / kFillSegments) * kTileW;
+    const uint32_t x0 = min(j * segment, vc.width), x1 = min(x0 + segment, vc.width);
+    // [x0, left_end) and [right_begin, x1): the segment without the box's columns
+    uint32_t left_end = x1, right_begin = x1;
+    if(r >= (box_rows & 0xffffu) && r <= (box_rows >> 16)) {
+        const uint32_t c0 = (box_cols & 0xffffu) * kTileW, c1 = min(((box_cols & 0xffffu) + (box_cols >> 16)) * kTileW, vc.width);
+        left_end = min(x1, max(x0, c0));
+        right_begin = max(x0, min(x1, c1));
+    }
+    const bool wide = (vc.width & 3u) == 0u && (reinterpret_cast<uintptr_t>(argb) & 15u) == 0u;
+    for(uint32_t k = wave; k < rows_per_group; k += waves) {
+        const uint32_t row = r * rows_per_group + k;
+        if(row >= vc.row_count) break;
+        const float4 colour = row_colour(image_row(vc, row));
+        const uint32_t word = pack_argb32(colour.x, colour.y, colour.z);
+        const size_t base = static_cast<size_t>(row) * vc.width;
+        for(int side = 0; side < 2; side++) {
+            const uint32_t xa = side == 0 ? x0 : right_begin, xb = side == 0 ? left_end : x1;
+            if(wide) {      // (the spans begin and end at multiples of the tile width or at the frame's edge)
+                uint4 *line = reinterpret_cast<uint4 *>(argb + base);
+                for(uint32_t q = (xa >> 2) + lane; q < (xb >> 2); q += 64u) line[q] = make_uint4(word, word, word, word);
+            } else {
+                for(uint32_t x = xa + lane; x < xb; x += 64u) argb[base + x] = word;
+            }
+            if(rgba) {
+                for(uint32_t x = xa + lane; x < xb; x += 64u) rgba[base + x] = colour;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // primary pass: the reference's pixel kernel, 4 horizontally adjacent pixels per lane so the
 // packed image leaves as one 16-byte store per lane (1 KiB per wave instruction)
 // ------------------------------------------------------------------------------------------
@@ -407,17 +453,32 @@ __device__ __forceinline__ f3 primary_pixel(const view_consts &vc, const camera_
     }
 }
 
+// box_rows / box_cols: the box of cells (kPrimaryBoxRows band rows by kTileW columns) outside of
+// which no pixel's ray comes within the screening margin of the sphere (sphere_box), columns
+// [bx0, bx1) of band rows [by0, by1) -- the whole band when there is no such box.  The first
+// compute_groups workgroups render the box's pixels; the rest write the rows' background around
+// it (fill_around_box): on the reference's 4K frame 78 % of the pixels, which then cost stores only.
+constexpr uint32_t kPrimaryBoxRows = 8;
 template <bool EXACT, bool VEC4>
 __global__ __launch_bounds__(kPrimaryBlock) void primary_kernel(view_consts vc, camera_consts cc,
                                                                  uint32_t *__restrict__ argb,
-                                                                 float4 *__restrict__ rgba) {
-    constexpr uint32_t PX = VEC4 ? 4u : 1u;
-    const uint32_t groups_per_row = vc.width / PX;
+                                                                 float4 *__restrict__ rgba, uint32_t box_rows, uint32_t box_cols,
+                                                                 uint32_t bx0, uint32_t bx1, uint32_t by0, uint32_t by1,
+                                                                 uint32_t compute_groups) {
+    constexpr uint32_t PX = VEC4 ? 4u : 1u;      // (2 or 1 a lane inside the box, for more and shorter waves: 7 % and 22 % slower)
+    if(blockIdx.x >= compute_groups) {
+        fill_around_box(vc, blockIdx.x - compute_groups, kPrimaryBoxRows, box_rows, box_cols, argb, rgba, [&](uint32_t y) {
+            const f3 bg = row_background<EXACT>(vc, y);
+            return make_float4(bg.x, bg.y, bg.z, 1.0f);
+        });
+        return;
+    }
+    const uint32_t groups_per_row = (bx1 - bx0) / PX;
     const uint32_t gid = blockIdx.x * kPrimaryBlock + threadIdx.x;
-    if(gid >= groups_per_row * vc.row_count) return;
+    if(gid >= groups_per_row * (by1 - by0)) return;
 
-    const uint32_t row = gid / groups_per_row;
-    const uint32_t x0 = (gid - row * groups_per_row) * PX;
+    const uint32_t row = by0 + gid / groups_per_row;
+    const uint32_t x0 = bx0 + (gid % groups_per_row) * PX;
     const uint32_t y = image_row(vc, row);
     const f3 bg = row_background<EXACT>(vc, y);
 
@@ -1635,47 +1696,13 @@ __device__ __forceinline__ f3 background_total(const view_consts &vc, uint32_t p
 
 // Fast build, one sphere: the background outside the box of workgroups in which the sphere can be
 // hit (sphere_box, host side), written by the last workgroups of the launch instead of by one
-// workgroup a tile.  Fill workgroup f takes segment f % kFillSegments of row f / kFillSegments of
-// workgroups, less the box's columns where the row is one of the box's; a wave takes every
-// fourth image row of it and writes the row's one colour over the span, 16 bytes a lane where
-// the frame's width and address allow.  (A 4K frame's background: 100,000 waves of 64 pixels each,
+// workgroup a tile (fill_around_box).  (A 4K frame's background: 100,000 waves of 64 pixels each,
 // 50 us of a launch bound by how fast waves start, against 540 workgroups that store at the
 // memory's rate.)
-constexpr uint32_t kFillSegments = 4;
 __device__ __forceinline__ void fill_background(const view_consts &vc, uint32_t f, uint32_t rows_per_group, uint32_t row_order,
                                                 uint32_t box_cols, uint32_t *__restrict__ argb, float4 *__restrict__ rgba) {
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, waves = blockDim.x >> 6;
-    const uint32_t r = f / kFillSegments, j = f - r * kFillSegments;
-    const uint32_t groups_x = (vc.width + kTileW - 1u) / kTileW;
-    const uint32_t segment = ((groups_x + kFillSegments - 1u) / kFillSegments) * kTileW;
-    const uint32_t x0 = min(j * segment, vc.width), x1 = min(x0 + segment, vc.width);
-    // [x0, left_end) and [right_begin, x1): the segment without the box's columns
-    uint32_t left_end = x1, right_begin = x1;
-    if(r >= (row_order & 0xffffu) && r <= (row_order >> 16)) {
-        const uint32_t c0 = (box_cols & 0xffffu) * kTileW, c1 = min(((box_cols & 0xffffu) + (box_cols >> 16)) * kTileW, vc.width);
-        left_end = min(x1, max(x0, c0));
-        right_begin = max(x0, min(x1, c1));
-    }
-    const bool wide = (vc.width & 3u) == 0u && (reinterpret_cast<uintptr_t>(argb) & 15u) == 0u;
-    for(uint32_t k = wave; k < rows_per_group; k += waves) {
-        const uint32_t row = r * rows_per_group + k;
-        if(row >= vc.row_count) break;
-        const float4 mean = mean_colour(vc, background_total(vc, image_row(vc, row)));
-        const uint32_t word = pack_argb32(mean.x, mean.y, mean.z);
-        const size_t base = static_cast<size_t>(row) * vc.width;
-        for(int side = 0; side < 2; side++) {
-            const uint32_t xa = side == 0 ? x0 : right_begin, xb = side == 0 ? left_end : x1;
-            if(wide) {      // (the spans begin and end at multiples of the tile width or at the frame's edge)
-                uint4 *line = reinterpret_cast<uint4 *>(argb + base);
-                for(uint32_t q = (xa >> 2) + lane; q < (xb >> 2); q += 64u) line[q] = make_uint4(word, word, word, word);
-            } else {
-                for(uint32_t x = xa + lane; x < xb; x += 64u) argb[base + x] = word;
-            }
-            if(rgba) {
-                for(uint32_t x = xa + lane; x < xb; x += 64u) rgba[base + x] = mean;
-            }
-        }
-    }
+    fill_around_box(vc, f, rows_per_group, row_order, box_cols, argb, rgba,
+                    [&](uint32_t y) { return mean_colour(vc, background_total(vc, y)); });
 }
 
 template <bool EXACT, bool ONE, bool FOLD, bool AXIAL, bool SKIP_LISTED, bool FAST_AFTER_DISC = false>
@@ -2747,12 +2774,25 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
 
     if(b->params.pass == AEHIP_PASS_PRIMARY) {
         const bool vec4 = (vc.width % 4u) == 0 && (reinterpret_cast<uintptr_t>(argb_dev) % 16u) == 0;
-        const uint64_t groups = static_cast<uint64_t>(vc.width / (vec4 ? 4u : 1u)) * vc.row_count;
-        const dim3 grid(static_cast<uint32_t>((groups + kPrimaryBlock - 1) / kPrimaryBlock));
-        if(exact && vec4) { func = reinterpret_cast<const void *>(primary_kernel<true, true>); hipLaunchKernelGGL((primary_kernel<true, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba); }
-        else if(exact) { func = reinterpret_cast<const void *>(primary_kernel<true, false>); hipLaunchKernelGGL((primary_kernel<true, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba); }
-        else if(vec4) { func = reinterpret_cast<const void *>(primary_kernel<false, true>); hipLaunchKernelGGL((primary_kernel<false, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba); }
-        else { func = reinterpret_cast<const void *>(primary_kernel<false, false>); hipLaunchKernelGGL((primary_kernel<false, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba); }
+        // the sphere's box of cells (kPrimaryBoxRows x kTileW pixels), or the whole band; around a box
+        // the launch's last workgroups write the rows' background
+        const uint32_t cells_x = (vc.width + kTileW - 1u) / kTileW, cells_y = (vc.row_count + kPrimaryBoxRows - 1u) / kPrimaryBoxRows;
+        uint32_t box_rows = 0, box_cols = 0, fill_groups = 0, bx0 = 0, bx1 = vc.width, by0 = 0, by1 = vc.row_count;
+        if(cells_x <= 0xffffu && cells_y <= 0xffffu && vc.n_spheres >= 1u && sphere_box(b, vc, kPrimaryBoxRows, cells_x, cells_y, &box_rows, &box_cols)) {
+            fill_groups = cells_y * kFillSegments;
+            bx0 = (box_cols & 0xffffu) * kTileW;
+            bx1 = std::min(((box_cols & 0xffffu) + (box_cols >> 16)) * static_cast<uint32_t>(kTileW), vc.width);
+            by0 = (box_rows & 0xffffu) * kPrimaryBoxRows;
+            by1 = std::min(((box_rows >> 16) + 1u) * kPrimaryBoxRows, vc.row_count);
+        }
+        const uint64_t box_w = bx1 - bx0, box_h = by1 - by0;
+        const uint64_t groups = box_w / (vec4 ? 4u : 1u) * box_h;
+        const uint32_t compute_groups = static_cast<uint32_t>((groups + kPrimaryBlock - 1) / kPrimaryBlock);
+        const dim3 grid(compute_groups + fill_groups);
+        if(exact && vec4) { func = reinterpret_cast<const void *>(primary_kernel<true, true>); hipLaunchKernelGGL((primary_kernel<true, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba, box_rows, box_cols, bx0, bx1, by0, by1, compute_groups); }
+        else if(exact) { func = reinterpret_cast<const void *>(primary_kernel<true, false>); hipLaunchKernelGGL((primary_kernel<true, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba, box_rows, box_cols, bx0, bx1, by0, by1, compute_groups); }
+        else if(vec4) { func = reinterpret_cast<const void *>(primary_kernel<false, true>); hipLaunchKernelGGL((primary_kernel<false, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba, box_rows, box_cols, bx0, bx1, by0, by1, compute_groups); }
+        else { func = reinterpret_cast<const void *>(primary_kernel<false, false>); hipLaunchKernelGGL((primary_kernel<false, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba, box_rows, box_cols, bx0, bx1, by0, by1, compute_groups); }
     } else if(b->all_terminal && vc.n_spheres <= static_cast<uint32_t>(kLdsSpheres)) {
         // waves per strip: as many as divide the pixel's sample blocks evenly (or nearly so)
         const uint32_t nblocks = (vc.spp + AEHIP_SAMPLE_BLOCK - 1u) / AEHIP_SAMPLE_BLOCK;
