@@ -1655,6 +1655,13 @@ struct timeline_stamp {
 
 // camera_body's split_and_tile argument: waves per strip (log2) in the low byte and
 constexpr uint32_t kCameraTiled = 0x100u;      // a workgroup owns a 16x16 tile and renders its strips in rounds
+// Listed pixels of the fast build: the reference's arithmetic beyond the discriminant too.  The
+// fast tail (hardware square root and reciprocals) leaves the hit distance t off by a few 1e-7
+// of itself, and the hit point minus the centre, of length r, takes that error times t: harmless
+// at t / r of a few (the reference's scene: 2 to 4), a few 1e-5 of the colour at 250.  Set where
+// the sphere is more than kFastTailMaxDistance radii from the camera.
+constexpr uint32_t kCameraExactTail = 0x200u;
+constexpr float kFastTailMaxDistance = 10.0f;
 
 // ------------------------------------------------------------------------------------------
 // camera pass: the path pass specialised for scenes in which every surface ends the path
@@ -1778,6 +1785,7 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
     // instructions in the reference's arithmetic at 1024 samples; in an eighth of a 4K frame the
     // other waves were done after 62 us and these after 84.)
     const bool halves = FAST_AFTER_DISC && pixel_list != nullptr && blocks_are_pairs_of_rows(vc);
+    const bool fast_tail = FAST_AFTER_DISC && (split_and_tile & kCameraExactTail) == 0u;       // the same in every lane
     const uint32_t half = halves ? lane >> 5 : 0u;
     if(pixel_list) {
         const uint32_t entry = halves ? (group_x * strips_per_group + strip) * 32u + (lane & 31u) : (group_x * strips_per_group + strip) * 64u + lane;
@@ -2013,17 +2021,24 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                                 if(disc >= 0.0f) {
                                     // FAST_AFTER_DISC: up to here the sample is the reference's, bit for
                                     // bit (ray, normalisation, discriminant -- where its rounding is
-                                    // amplified); from here on nothing amplifies, and the hardware's
-                                    // approximate square root and reciprocals are within 1e-6 of it
-                                    const float sq = FAST_AFTER_DISC ? __builtin_amdgcn_sqrtf(disc) : rt_sqrt<true>(disc);
-                                    const float inv_a2 = FAST_AFTER_DISC ? __builtin_amdgcn_rcpf(a2) : 0.0f;
-                                    float t = FAST_AFTER_DISC ? (-b - sq) * inv_a2 : (-b - sq) / a2;
+                                    // amplified); from here on only t / r amplifies, and for a sphere
+                                    // within kFastTailMaxDistance radii the hardware's approximate
+                                    // square root and reciprocals stay within 2e-6 of it (fast_tail)
+                                    float sq, inv_a2 = 0.0f, t;
+                                    if(fast_tail) {
+                                        sq = __builtin_amdgcn_sqrtf(disc);
+                                        inv_a2 = __builtin_amdgcn_rcpf(a2);
+                                        t = (-b - sq) * inv_a2;
+                                    } else {
+                                        sq = rt_sqrt<true>(disc);
+                                        t = (-b - sq) / a2;
+                                    }
                                     bool ok = (t > kTMin) && (t < closest);
                                     if(!ok) {
                                         // rare (camera inside a sphere): keep it a branch -- computed
                                         // unconditionally, the second IEEE division costs every hit 13 issue slots
                                         asm volatile("");
-                                        t = FAST_AFTER_DISC ? (-b + sq) * inv_a2 : (-b + sq) / a2;
+                                        t = fast_tail ? (-b + sq) * inv_a2 : (-b + sq) / a2;
                                         ok = (t > kTMin) && (t < closest);
                                     }
                                     if(ok) {
@@ -2035,7 +2050,7 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                             if(hit >= 0) {
                                 const f3 ctr = ONE ? f3{cc.center[0], cc.center[1], cc.center[2]}
                                                    : f3{s_ctr[hit].x, s_ctr[hit].y, s_ctr[hit].z};
-                                if constexpr(FAST_AFTER_DISC) {
+                                if(fast_tail) {
                                     const f3 w = {__builtin_fmaf(d.x, closest, cam.x - ctr.x), __builtin_fmaf(d.y, closest, cam.y - ctr.y),
                                                   __builtin_fmaf(d.z, closest, cam.z - ctr.z)};
                                     const float half_inv = 0.5f * __builtin_amdgcn_rsqf(dot3<false>(w, w));
@@ -2817,7 +2832,9 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         // the rows of workgroups in which the sphere can be hit, for the fast build's order of rows
         // (edges_first_row; the exact build, whose strips cost much the same wherever they are, keeps plain order)
         const uint32_t row_order = one && !exact && grid.y <= 0xffffu ? sphere_group_rows(b, vc, rows_per_group, grid.y) : 1u;
-        const uint32_t split_arg = split_log2 | (tiled ? kCameraTiled : 0u);
+        // (oc.oc = c + r*r: the sphere's distance from the camera against its radius)
+        const bool exact_tail = one && b->cc.c + b->cc.radius2 > kFastTailMaxDistance * kFastTailMaxDistance * b->cc.radius2;
+        const uint32_t split_arg = split_log2 | (tiled ? kCameraTiled : 0u) | (exact_tail ? kCameraExactTail : 0u);
         const bool fold = (vc.flags & kFlagFoldScreen) != 0;
 #define AEHIP_LAUNCH_CAMERA(E, O, F, A)                                                                                \
     do {                                                                                                               \
