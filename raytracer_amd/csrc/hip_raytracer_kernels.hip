@@ -317,6 +317,7 @@ struct camera_consts {       // travels as a kernel argument (SGPRs)
     float shade_scale;       // 0.5 / r
     float shade_offset[3];   // 0.5 - 0.5 * oc / r
     uint32_t near_root_only; // camera outside the sphere by more than t_min: a hit is the near root
+    uint32_t short_exact_ok; // exact build: pixels all of whose samples hit may take the loop without tests (camera_body)
     float radius2;           // r*r
 };
 
@@ -1816,6 +1817,9 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                         cls |= pc.faces_sphere ? (pc.newton_flat_ok ? (kNewton | kNewtonFlat) : pc.newton_ok ? kNewton : pc.newton_twice_ok ? (kNewton | kNewtonTwice) : kSureHit)
                                                : kCulled;    // behind the camera: no root counts
                 }
+                if constexpr(EXACT) {
+                    if(cc.short_exact_ok != 0u && pc.may_hit && pc.well_conditioned && pc.faces_sphere) cls |= kSureHit;
+                }
                 if(vc.flags & AEHIP_FLAG_WALK_ALL) cls &= kListed;      // every pixel through the general loop
                 strip_work = __ballot(valid && (cls & (kCulled | kListed)) == 0u) != 0ull;
                 if(!strip_work && valid && (cls & kListed) == 0u) store_pixel(x, row, all_miss_total(y));
@@ -1938,10 +1942,44 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
     };
 
     if constexpr(EXACT) {
+        // Exact build, one sphere, a wave all of whose pixels are hit by every sample, well conditioned,
+        // at the near root beyond t_min (classify_pixel; short_exact_ok): the reference's sample without
+        // the screening, the sign and range tests and the choice between hit and background --
+        // they are decided -- and with the square root and the division through the short sequences
+        // of rt_exact_math.h, whose operands are in range here.  The same operations on the same
+        // values as the general loop below, so the same bits; 15 of its 150 instructions a sample fewer.
+        bool wave_sure = false;
+        if constexpr(ONE && !FAST_AFTER_DISC) wave_sure = pixel_list == nullptr && __ballot(valid && !sure_hit) == 0ull && __ballot(valid) != 0ull;
         for(uint32_t first = 0; first < nblocks; first += split) {      // a round: `split` consecutive blocks
             const uint32_t blk = first + part;
             f3 block = {0.0f, 0.0f, 0.0f};
-            if(blk < nblocks && work) {
+            if(blk < nblocks && wave_sure) {
+                const f3 oc = {cc.oc[0], cc.oc[1], cc.oc[2]};
+                const f3 ctr = {cc.center[0], cc.center[1], cc.center[2]};
+                const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
+                const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
+                for(uint32_t s = s0; s < s1;) {
+                    const cell_row cr = row_at(s, s1);
+                    s += cr.count;
+                    const float py = yf + cr.jy;
+                    const float draw_y = (py * vc.psy - vc.vh_half) - cam.y;      // src/software_raytracer.cpp:218-221
+                    float cell = cr.first;
+                    for(uint32_t k = 0; k < cr.count; k++, cell += 1.0f) {
+                        const float jx = jitter ? (cell + off.rx) * cr.inv_cells : 0.5f;
+                        const float px = xf + jx;
+                        const f3 d = normalize3<true>(f3{(px * vc.psx - vc.vw_half) - cam.x, draw_y, dz});
+                        const float a = dot3<true>(d, d);                   // src/shapes.cpp:14-25
+                        const float b = -2.0f * dot3<true>(d, oc);
+                        const float disc = b * b - (4.0f * a) * cc.c;
+                        const float t = rt_exact::div_tame(-b - rt_exact::sqrt_tame(disc), 2.0f * a);
+                        const f3 pt = {d.x * t + cam.x, d.y * t + cam.y, d.z * t + cam.z};
+                        const f3 n = normalize3<true>(f3{pt.x - ctr.x, pt.y - ctr.y, pt.z - ctr.z});
+                        block.x += remap_unit(n.x);
+                        block.y += remap_unit(n.y);
+                        block.z += remap_unit(n.z);
+                    }
+                }
+            } else if(blk < nblocks && work) {
                 const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
                 const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
                 for(uint32_t s = s0; s < s1;) {
@@ -3258,6 +3296,12 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
             b->cc.shade_offset[1] = static_cast<float>(0.5 - 0.5 * ky / r0);
             b->cc.shade_offset[2] = static_cast<float>(0.5 - 0.5 * static_cast<double>(ocz) / r0);
             b->cc.near_root_only = std::sqrt(static_cast<double>(occ)) - r0 > 1.001 * static_cast<double>(kTMin) ? 1u : 0u;
+            // the near root is beyond t_min with a factor to spare whatever the roundings, and the operands
+            // of the hit's square root and division are inside the ranges of rt_exact_math.h: a
+            // well-conditioned hit has discriminant >= 1e-3 oc.oc (classify_pixel's bound with
+            // big >= dd (oc.oc + r*r) >= 2 dd |oc| r), and -b - sqrt(disc) lies between twice the near root and 4 |oc|
+            const double distance = std::sqrt(static_cast<double>(occ));
+            b->cc.short_exact_ok = (distance - r0 > 4.0 * static_cast<double>(kTMin) && distance >= 0x1p-30 && distance <= 0x1p+36) ? 1u : 0u;
             b->cc.radius2 = geom[0].w;
         }
         // the table of camera entries goes up in the packed layout of load_camera_group: whole
