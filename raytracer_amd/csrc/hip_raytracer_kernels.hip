@@ -1956,6 +1956,7 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
             if(blk < nblocks && wave_sure) {
                 const f3 oc = {cc.oc[0], cc.oc[1], cc.oc[2]};
                 const f3 ctr = {cc.center[0], cc.center[1], cc.center[2]};
+                const bool straight_ahead = cc.oc[0] == 0.0f && cc.oc[1] == 0.0f && dz != 0.0f;     // (short_exact_ok: |oc| >= 2^-30, so oc.z != 0)
                 const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
                 const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
                 for(uint32_t s = s0; s < s1;) {
@@ -1969,7 +1970,8 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                         const float px = xf + jx;
                         const f3 d = normalize3<true>(f3{(px * vc.psx - vc.vw_half) - cam.x, draw_y, dz});
                         const float a = dot3<true>(d, d);                   // src/shapes.cpp:14-25
-                        const float b = -2.0f * dot3<true>(d, oc);
+                        // (centre straight ahead of the camera: (d.x*0 + d.y*0) + d.z*oc.z is d.z*oc.z, a zero added to a non-zero)
+                        const float b = -2.0f * (straight_ahead ? d.z * oc.z : dot3<true>(d, oc));
                         const float disc = b * b - (4.0f * a) * cc.c;
                         const float t = rt_exact::div_tame(-b - rt_exact::sqrt_tame(disc), 2.0f * a);
                         const f3 pt = {d.x * t + cam.x, d.y * t + cam.y, d.z * t + cam.z};
