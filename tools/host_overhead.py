@@ -30,28 +30,23 @@ def main():
     side = torch.cuda.Stream(device=device)
     torch.cuda.set_stream(side)
     W, H = 3840, 2160
-    g = BandGather(W, H, device)
-    # force the multi-rank code path on the single rank: received bands stacked, rows reordered
-    g.world = 1
-    recv = torch.zeros((1, g.max_rows, W), dtype=torch.int32, device=device)
-    image = g.image
-    order = torch.arange(H, dtype=torch.int64, device=device)
+    # the multi-rank code path on the single rank, on a frame as large as one rank's share of 8 (4 MB gathered and
+    # put in row order a frame), so that the GPU is done long before the host
+    g = BandGather(W, 270, device, always_collective=True)
     back = rt.HipRaytracer(None, device=0)
-    assert back.setup(W, H, spp=1, max_depth=1, seed=1, flags=rt.FLAG_FAST, pass_=rt.PASS_PATH, row_begin=0, row_count=270)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.frames)]
+    assert back.setup(W, 270, spp=1, max_depth=1, seed=1, flags=rt.FLAG_FAST, pass_=rt.PASS_PATH)
+    sides = [side, torch.cuda.Stream(device=device)]
+    handles = [s.cuda_stream for s in sides]
 
     def loop(n):
-        pending = None
+        # bench.py's timed loop for several ranks: frames on two streams in turn, gather submitted behind each
         for i in range(n):
-            band = g.locals[i & 1]
-            ev[i][0].record()
-            back.trace_device(band.data_ptr(), None, side.cuda_stream)
-            ev[i][1].record()
-            if pending is not None:
-                pending.wait()
-                torch.index_select(recv.view(g.max_rows, W), 0, order, out=image)
-            pending = dist.gather(band, [recv[0]], dst=0, async_op=True)
-        pending.wait()
+            torch.cuda.set_stream(sides[i & 1])
+            band = g.begin(i)
+            back.trace_device(band.data_ptr(), None, handles[i & 1])
+            g.submit(i)
+        torch.cuda.set_stream(sides[0])
+        g.finish()
 
     loop(20)
     torch.cuda.synchronize()
@@ -61,7 +56,7 @@ def main():
     torch.cuda.synchronize()
     total = time.perf_counter() - t0
     print(f"host time per frame {host / a.frames * 1e3:.3f} ms; with the GPU drained {total / a.frames * 1e3:.3f} ms "
-          f"({a.frames} frames, 4K image, 270-row band, 1 spp)")
+          f"({a.frames} frames of 3840x270, 1 spp)")
     dist.destroy_process_group()
 
 
