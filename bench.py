@@ -281,8 +281,9 @@ def main():
         walk_all: every sample of every pixel goes through the sample loop (AEHIP_FLAG_WALK_ALL)."""
         flags = rt.FLAG_JITTER | (rt.FLAG_FAST if mode == "fast" else 0) | (rt.FLAG_WALK_ALL if walk_all else 0)
         back = rt.HipRaytracer(None, device=dev_index)
-        if not back.setup(WIDTH, HEIGHT, spp=args.spp, max_depth=args.depth, seed=1, flags=flags, pass_=rt.PASS_PATH,
-                          **gather.band):
+        # frames are timed by this loop's own events: the library records none of its own (FLAG_NO_TIMING)
+        if not back.setup(WIDTH, HEIGHT, spp=args.spp, max_depth=args.depth, seed=1, flags=flags | rt.FLAG_NO_TIMING,
+                          pass_=rt.PASS_PATH, **gather.band):
             sys.exit("setup failed: " + back.last_error())
         for _ in range(warmup):
             back.trace_device(gather.local.data_ptr(), None, stream)
@@ -297,18 +298,19 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            on = None
+            on = side = None
             if sides is not None:
-                torch.cuda.set_stream(sides[i % len(sides)])
+                side = sides[i % len(sides)]
+                torch.cuda.set_stream(side)
                 on = handles[i % len(sides)]
-            band = gather.begin(i) if overlap else gather.local
+            band = gather.begin(i, side) if overlap else gather.local
             if every or i == 0:
                 ev[i][0].record()               # alternating band buffers: the gather of frame i
             back.trace_device(band.data_ptr(), None, on)        # overlaps the render of frame i+1
             if every or i == steps - 1:
                 ev[i][1].record()
             if overlap:
-                gather.submit(i)
+                gather.submit(i, side)
             else:
                 gather.gather()
         if sides is not None:

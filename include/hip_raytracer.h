@@ -48,11 +48,16 @@ enum {
     AEHIP_FLAG_NO_REGEN   = 8u,  /* measurement aid: a lane whose path ended waits until every
                                     lane of its wave is done before starting its next sample
                                     (the image is unchanged; only lane utilisation differs)  */
-    AEHIP_FLAG_WALK_ALL   = 16u  /* measurement aid: the single-sphere camera pass walks every
+    AEHIP_FLAG_WALK_ALL   = 16u, /* measurement aid: the single-sphere camera pass walks every
                                     sample of every pixel instead of deciding, from bounds over
                                     the pixel's sample positions, the pixels whose samples all
                                     miss (and, fast build, all hit).  Exact build: the image is
                                     unchanged bit for bit; fast build: within its tolerance   */
+    AEHIP_FLAG_NO_TIMING  = 32u  /* aehip_backend_trace_device[_static] record no timing events
+                                    around the launch (two event records cost the host 7 us and
+                                    the queue two barriers: as much as a short frame's launch);
+                                    aehip_stats.kernel_ms then reads 0.  For callers that time
+                                    frames themselves.  The image is unchanged                */
 };
 
 enum {
@@ -111,7 +116,8 @@ typedef struct aehip_params {
 } aehip_params;
 
 typedef struct aehip_stats {
-    float    kernel_ms;     /* device time of the last trace's kernel(s), from HIP events */
+    float    kernel_ms;     /* device time of the last trace's kernel(s), from HIP events
+                               (0 with AEHIP_FLAG_NO_TIMING)                                */
     float    copy_ms;       /* device->host copy of the last aehip_backend_trace           */
     uint64_t rays;          /* ray segments (only with AEHIP_FLAG_COUNT_RAYS)              */
     uint64_t paths;         /* width * rows * spp of the last trace                        */

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RAYTRACER_AMD_LIB") or os.path.join(_HERE, "lib", "libhip_raytracer.so")
 
 MAT_NORMAL, MAT_LAMBERT, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2, 3
-FLAG_JITTER, FLAG_FAST, FLAG_COUNT_RAYS, FLAG_NO_REGEN, FLAG_WALK_ALL = 1, 2, 4, 8, 16
+FLAG_JITTER, FLAG_FAST, FLAG_COUNT_RAYS, FLAG_NO_REGEN, FLAG_WALK_ALL, FLAG_NO_TIMING = 1, 2, 4, 8, 16, 32
 PASS_PRIMARY, PASS_PATH = 0, 1
 
 SPHERE_DTYPE = np.dtype(

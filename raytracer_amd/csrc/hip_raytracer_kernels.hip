@@ -3413,10 +3413,11 @@ int aehip_backend_trace_device(aehip_backend *b, uint32_t *argb_dev, float *rgba
     AEHIP_CHECK(hipSetDevice(b->device));
     const bool own = hip_stream == nullptr;
     hipStream_t stream = own ? b->stream : static_cast<hipStream_t>(hip_stream);
-    AEHIP_CHECK(hipEventRecord(b->ev_begin, stream));
+    const bool timed = (b->vc.flags & AEHIP_FLAG_NO_TIMING) == 0u;
+    if(timed) AEHIP_CHECK(hipEventRecord(b->ev_begin, stream));
     const int rc = launch(b, argb_dev, rgba_dev, stream, own_scratch(b));
     if(rc != AEHIP_OK) return rc;
-    AEHIP_CHECK(hipEventRecord(b->ev_end, stream));
+    if(timed) AEHIP_CHECK(hipEventRecord(b->ev_end, stream));
     b->timed_on_own_stream = own;
     if(own) AEHIP_CHECK(hipStreamSynchronize(stream));
     return AEHIP_OK;
@@ -3445,10 +3446,11 @@ int aehip_backend_trace_device_static(aehip_backend *b, uint32_t *argb_dev, floa
     }
     const bool own = hip_stream == nullptr;
     hipStream_t stream = own ? b->stream : static_cast<hipStream_t>(hip_stream);
-    AEHIP_CHECK(hipEventRecord(b->ev_begin, stream));
+    const bool timed = (b->vc.flags & AEHIP_FLAG_NO_TIMING) == 0u;
+    if(timed) AEHIP_CHECK(hipEventRecord(b->ev_begin, stream));
     const int rc = launch(b, argb_dev, rgba_dev, stream, sc);
     if(rc != AEHIP_OK) return rc;
-    AEHIP_CHECK(hipEventRecord(b->ev_end, stream));
+    if(timed) AEHIP_CHECK(hipEventRecord(b->ev_end, stream));
     b->timed_on_own_stream = own;
     if(own) AEHIP_CHECK(hipStreamSynchronize(stream));
     return AEHIP_OK;
@@ -3541,9 +3543,14 @@ int aehip_backend_trace(aehip_backend *b) {
 int aehip_backend_stats(aehip_backend *b, aehip_stats *out) {
     if(!b || !out) return fail(AEHIP_E_INVALID, "aehip_backend_stats: null argument");
     AEHIP_CHECK(hipSetDevice(b->device));
-    AEHIP_CHECK(hipEventSynchronize(b->ev_end));
     float ms = 0.0f;
-    AEHIP_CHECK(hipEventElapsedTime(&ms, b->ev_begin, b->ev_end));
+    if(b->vc.flags & AEHIP_FLAG_NO_TIMING) {
+        // no events to wait on: the device's work is the only ordering there is (the counters below are read after it)
+        AEHIP_CHECK(hipDeviceSynchronize());
+    } else {
+        AEHIP_CHECK(hipEventSynchronize(b->ev_end));
+        AEHIP_CHECK(hipEventElapsedTime(&ms, b->ev_begin, b->ev_end));
+    }
     b->stats.kernel_ms = ms;
     if((b->vc.flags & AEHIP_FLAG_COUNT_RAYS) && b->counts_known) {
         b->stats.rays = b->known_rays;

@@ -147,22 +147,24 @@ class BandGather:
 
     # ------------------------------------------------------------------ overlapped form
 
-    def begin(self, frame: int) -> torch.Tensor:
-        """Buffer to render `frame` into.  Waits (stream-side) for the gather that last read it."""
+    def begin(self, frame: int, stream: "torch.cuda.Stream | None" = None) -> torch.Tensor:
+        """Buffer to render `frame` into.  Waits (stream-side) for the gather that last read it.
+        `stream`: the current stream, for callers that have it at hand (looking it up costs 3 us)."""
         slot = frame & 1
         self._complete(slot)
         if self._free[slot] is not None:
-            torch.cuda.current_stream().wait_event(self._free[slot])
+            (stream if stream is not None else torch.cuda.current_stream()).wait_event(self._free[slot])
         return self.locals[slot]
 
-    def submit(self, frame: int) -> None:
+    def submit(self, frame: int, stream: "torch.cuda.Stream | None" = None) -> None:
         """Starts the gather of the band rendered into begin(frame)'s buffer and returns at once.
         At most one gather is in flight: the previous frame's gather, which had that frame's
         successor render to hide behind, is completed (and its rows put in image order) first, so
-        frames land in the destination image in order on any backend."""
+        frames land in the destination image in order on any backend.
+        `stream`: the current stream (the one the band was rendered on), as for begin()."""
         slot = frame & 1
         if self._stream_ordered:
-            render_stream = torch.cuda.current_stream()
+            render_stream = stream if stream is not None else torch.cuda.current_stream()
             self._rendered[slot].record(render_stream)
             torch.cuda.set_stream(self._comm_stream)        # (set_stream twice: 1 us; the context manager: 7)
             try:

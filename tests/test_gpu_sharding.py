@@ -71,23 +71,29 @@ def test_frames_arrive_whole_and_in_order_with_frames_on_alternating_streams(sin
     assert bool((image == frames).all())
 
 
-def test_rendered_frames_through_the_two_stream_pipeline_equal_the_single_launch(single_rank_rccl):
+@pytest.mark.parametrize("untimed", [False, True])
+def test_rendered_frames_through_the_two_stream_pipeline_equal_the_single_launch(single_rank_rccl, untimed):
+    """untimed: the benchmark's form of the loop -- the library records no timing events
+    (AEHIP_FLAG_NO_TIMING) and begin() / submit() are handed the stream instead of looking it up."""
     import torch
 
     device = torch.device("cuda", 0)
     width, height = 1280, 720
     g = BandGather(width, height, device, always_collective=True)
     back = rt.HipRaytracer(None, device=0)
-    flags = rt.FLAG_JITTER
+    flags = rt.FLAG_JITTER | (rt.FLAG_NO_TIMING if untimed else 0)
     assert back.setup(width, height, spp=16, max_depth=1, seed=3, flags=flags, pass_=rt.PASS_PATH, **g.band), back.last_error()
     streams = [torch.cuda.Stream(device=device) for _ in range(2)]
     for i in range(7):
-        torch.cuda.set_stream(streams[i & 1])
-        band = g.begin(i)
-        back.trace_device(band.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
-        g.submit(i)
+        side = streams[i & 1]
+        torch.cuda.set_stream(side)
+        band = g.begin(i, side if untimed else None)
+        back.trace_device(band.data_ptr(), None, side.cuda_stream)
+        g.submit(i, side if untimed else None)
     image = g.finish()
     torch.cuda.synchronize()
+    st = back.stats()
+    assert (st.kernel_ms == 0.0) if untimed else (st.kernel_ms > 0.0)
     back.close()
     whole, _ = rt.render(width, height, spp=16, max_depth=1, seed=3, jitter=True)
     np.testing.assert_array_equal(image.cpu().numpy().view(np.uint32), whole)

@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--timed", action="store_true", help="the loop as it was before: library timing events, streams looked up")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -34,17 +35,19 @@ def main():
     # put in row order a frame), so that the GPU is done long before the host
     g = BandGather(W, 270, device, always_collective=True)
     back = rt.HipRaytracer(None, device=0)
-    assert back.setup(W, 270, spp=1, max_depth=1, seed=1, flags=rt.FLAG_FAST, pass_=rt.PASS_PATH)
+    # --timed: the library's own timing events around every launch, as callers without AEHIP_FLAG_NO_TIMING get them
+    assert back.setup(W, 270, spp=1, max_depth=1, seed=1, flags=rt.FLAG_FAST | (0 if a.timed else rt.FLAG_NO_TIMING), pass_=rt.PASS_PATH)
     sides = [side, torch.cuda.Stream(device=device)]
     handles = [s.cuda_stream for s in sides]
 
     def loop(n):
         # bench.py's timed loop for several ranks: frames on two streams in turn, gather submitted behind each
         for i in range(n):
-            torch.cuda.set_stream(sides[i & 1])
-            band = g.begin(i)
+            side = sides[i & 1]
+            torch.cuda.set_stream(side)
+            band = g.begin(i, None if a.timed else side)
             back.trace_device(band.data_ptr(), None, handles[i & 1])
-            g.submit(i)
+            g.submit(i, None if a.timed else side)
         torch.cuda.set_stream(sides[0])
         g.finish()
 

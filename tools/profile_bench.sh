@@ -16,7 +16,12 @@ if [ "$3" = walked ]; then KEY=${KEY}_walked; EXTRA=--walk-all; fi
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --mode $MODE --steps $STEPS --warmup $WARMUP --no-cpu-baseline --no-aux --no-second-mode $EXTRA"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1 || exit 1
+# the kernel trace runs bench.py's own default frame counts (200 timed after 50 of warm-up): the GPU's clocks settle only
+# after a few milliseconds of load, and a 30-frame run of the fast build averages 0.43 ms a launch where the default run
+# averages 0.36-0.37, in the profiler's trace and in bench.py's own events alike.  The counter passes keep the short
+# run: they serialise launches anyway and the counts do not depend on the clock.
+TRACED="python3 $ROOT/bench.py --mode $MODE --no-cpu-baseline --no-aux --no-second-mode $EXTRA"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $TRACED > "$OUT/trace.log" 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY -d "$OUT/pmc_sq" -o pmc -- $BENCH > "$OUT/pmc_sq.log" 2>&1 || exit 2
 timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_SMEM GRBM_GUI_ACTIVE -d "$OUT/pmc_flops" -o pmc -- $BENCH > "$OUT/pmc_flops.log" 2>&1 || exit 5
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o pmc -- $BENCH > "$OUT/pmc_fetch.log" 2>&1 || exit 3
