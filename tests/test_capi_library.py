@@ -60,6 +60,31 @@ def test_field_offsets_match_the_compiled_header(tmp_path):
     assert got[("aehip_sphere", "size")] == raytracer_amd.SPHERE_DTYPE.itemsize
 
 
+def test_enum_values_match_the_compiled_header(tmp_path):
+    """Flags, passes and materials as the header's compiler sees them against the Python constants."""
+    import subprocess
+
+    names = {"AEHIP_FLAG_JITTER": raytracer_amd.FLAG_JITTER, "AEHIP_FLAG_FAST": raytracer_amd.FLAG_FAST,
+             "AEHIP_FLAG_COUNT_RAYS": raytracer_amd.FLAG_COUNT_RAYS, "AEHIP_FLAG_NO_REGEN": raytracer_amd.FLAG_NO_REGEN,
+             "AEHIP_FLAG_WALK_ALL": raytracer_amd.FLAG_WALK_ALL, "AEHIP_FLAG_NO_TIMING": raytracer_amd.FLAG_NO_TIMING,
+             "AEHIP_PASS_PRIMARY": raytracer_amd.PASS_PRIMARY, "AEHIP_PASS_PATH": raytracer_amd.PASS_PATH,
+             "AEHIP_MAT_NORMAL": raytracer_amd.MAT_NORMAL, "AEHIP_MAT_LAMBERT": raytracer_amd.MAT_LAMBERT,
+             "AEHIP_MAT_METAL": raytracer_amd.MAT_METAL, "AEHIP_MAT_DIELECTRIC": raytracer_amd.MAT_DIELECTRIC}
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    declared = set(re.findall(r"\b(AEHIP_(?:FLAG|PASS|MAT)_[A-Z_]+)\s*=", text))
+    assert declared == set(names), "an enumerator of the header has no Python constant (or the other way round)"
+    lines = ['#include <stdio.h>', '#include "hip_raytracer.h"', "int main(void) {"]
+    lines += [f'  printf("{n} %ld\\n", (long){n});' for n in names]
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "enums.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "enums"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.dirname(HEADER), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = {l.split()[0]: int(l.split()[1]) for l in out if l}
+    assert got == names
+
+
 def test_null_arguments_are_rejected_without_touching_a_device():
     lib = raytracer_amd.load()
     assert lib.aehip_backend_create(0, None, None) == -2
