@@ -275,6 +275,7 @@ def main():
     overlap = not share                 # gloo's asynchronous gather of device tensors does not complete here
 
     verified = {}
+    kept_columns = {}
 
     def timed_run(mode, steps, warmup, walk_all=False):
         """K steps of render-band + gather; returns (elapsed_s max over ranks, kernel_s max over ranks, stats).
@@ -282,9 +283,17 @@ def main():
         flags = rt.FLAG_JITTER | (rt.FLAG_FAST if mode == "fast" else 0) | (rt.FLAG_WALK_ALL if walk_all else 0)
         back = rt.HipRaytracer(None, device=dev_index)
         # frames are timed by this loop's own events: the library records none of its own (FLAG_NO_TIMING)
-        if not back.setup(WIDTH, HEIGHT, spp=args.spp, max_depth=args.depth, seed=1, flags=flags | rt.FLAG_NO_TIMING,
+        if not back.setup(WIDTH, HEIGHT, spp=args.spp, max_depth=args.depth, seed=1, flags=flags | (0 if share else rt.FLAG_NO_TIMING),
                           pass_=rt.PASS_PATH, **gather.band):
             sys.exit("setup failed: " + back.last_error())
+        # what crosses the links: the columns outside of which a band row is one colour stay at home (every rank's
+        # library derives the same columns from the scene, the camera and the frame's size)
+        c0, c1 = back.background_columns()
+        # (not in the shared-GPU rehearsal: gloo's gather of device tensors between two processes on one GPU does not
+        # complete with the narrow buffers -- nor after any other gloo collective -- on this image; over CPU tensors
+        # the same exchange is covered by tests/test_sharding_gloo.py, over RCCL by tests/test_gpu_sharding.py)
+        narrow = not share and gather.set_columns(c0, c1)
+        kept_columns[mode + ("_every_sample_walked" if walk_all else "")] = [c0, c1] if narrow else None
         for _ in range(warmup):
             back.trace_device(gather.local.data_ptr(), None, stream)
             gather.gather()
@@ -407,6 +416,9 @@ def main():
             "kernel_ms": kernel_s * 1e3,
             "device": device_facts(torch, dev_index),
             "gathered_frame_equals_single_gpu_frame": verified,
+            "gather": {"ranks": world, "band_rows": gather.max_rows,
+                       "kept_columns": kept_columns,       # per run: the columns a rank sends (plus one background pixel a row), None = whole rows
+                       "bytes_per_peer_per_frame": {k: gather.max_rows * 4 * ((v[1] - v[0] + 1) if v else WIDTH) for k, v in kept_columns.items()}},
             "rays_per_s": paths_total / (elapsed / args.steps),
             "roofline": roofline_of(args.mode, kernel_s, st, args.walk_all),
         }

@@ -177,6 +177,18 @@ int aehip_backend_trace_device_static(aehip_backend *backend, uint32_t *argb_dev
 
 int aehip_backend_stats(aehip_backend *backend, aehip_stats *out);
 
+/* Columns [*col_begin, *col_end) of the band outside of which every pixel is its row's background:
+ * no sample position of such a pixel sends a ray within reach of a shape, so in every band row all
+ * of them hold one and the same colour (the reference's row gradient, src/software_raytracer.cpp:
+ * 210-215, which is also what its tiles outside the sphere hold).  Known for scenes of one sphere
+ * (the reference's), from the same bound the kernels use to leave those pixels to their
+ * background writers; (0, width) otherwise.  The columns follow from the scene, the camera and the
+ * frame's size -- not from the band, the seed, the sample count or AEHIP_FLAG_* -- so the GPUs that
+ * render the bands of one frame report the same columns.  For callers that move bands between
+ * GPUs: those columns and one pixel of background a row are all a peer needs to send.  No
+ * counterpart in the reference, whose frame never leaves one address space. */
+int aehip_backend_background_columns(aehip_backend *backend, uint32_t *col_begin, uint32_t *col_end);
+
 /* One frame on `n_devices` GPUs of this node, driven from the calling thread; the multi-GPU form
  * of setup() + trace() (src/raytracer.h:25-26) for a host program that is one process, as the
  * reference is (src/main.cpp:11-25).  The rows params->row_begin .. +row_count (0 = all) are cut

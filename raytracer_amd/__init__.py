@@ -87,6 +87,7 @@ EXPORTS = (
     "aehip_backend_trace_device",
     "aehip_backend_trace_device_static",
     "aehip_backend_stats",
+    "aehip_backend_background_columns",
     "aehip_trace_frame",
     "aehip_frame_band",
 )
@@ -128,6 +129,7 @@ def load() -> ctypes.CDLL:
         L.aehip_backend_trace_device.argtypes = [vp, vp, vp, vp]
         L.aehip_backend_trace_device_static.argtypes = [vp, vp, vp, vp]
         L.aehip_backend_stats.argtypes = [vp, ctypes.POINTER(AehipStats)]
+        L.aehip_backend_background_columns.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
         L.aehip_trace_frame.argtypes = [ctypes.c_int, ctypes.POINTER(AehipScene), ctypes.POINTER(AehipParams), vp,
                                         ctypes.POINTER(AehipStats)]
         L.aehip_frame_band.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int] + [ctypes.POINTER(ctypes.c_uint32)] * 3
@@ -216,6 +218,12 @@ class HipRaytracer:
         st = AehipStats()
         _check(self._lib.aehip_backend_stats(self._h, ctypes.byref(st)), "aehip_backend_stats")
         return st
+
+    def background_columns(self) -> tuple[int, int]:
+        """(col_begin, col_end): outside these columns every pixel of a band row is the row's background."""
+        c0, c1 = ctypes.c_uint32(), ctypes.c_uint32()
+        _check(self._lib.aehip_backend_background_columns(self._h, ctypes.byref(c0), ctypes.byref(c1)), "aehip_backend_background_columns")
+        return c0.value, c1.value
 
     def close(self) -> None:
         if self._h:

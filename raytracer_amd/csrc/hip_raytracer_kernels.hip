@@ -3540,6 +3540,28 @@ int aehip_backend_trace(aehip_backend *b) {
     return AEHIP_OK;
 }
 
+int aehip_backend_background_columns(aehip_backend *b, uint32_t *col_begin, uint32_t *col_end) {
+    if(!b || !col_begin || !col_end) return fail(AEHIP_E_INVALID, "aehip_backend_background_columns: null argument");
+    if(!b->ready) return fail(AEHIP_E_NOT_SETUP, "aehip_backend_background_columns before a successful setup");
+    // the whole frame's rows, whatever the band: every band of one frame gets the same answer
+    view_consts vc = b->vc;
+    vc.row_begin = 0;
+    vc.row_count = vc.height;
+    vc.tile_rows = 0;
+    vc.tile_stride = 0;
+    *col_begin = 0;
+    *col_end = vc.width;
+    // one sphere: the box of 16-pixel columns outside of which no sample position of any pixel comes within the
+    // screening margin of the sphere (the box the kernels themselves leave to their background writers)
+    const uint32_t groups_x = (vc.width + kTileW - 1) / kTileW, groups_y = (vc.row_count + 3u) / 4u;
+    uint32_t rows = 0, cols = 0;
+    if(vc.n_spheres == 1u && groups_x <= 0xffffu && groups_y <= 0xffffu && groups_y >= 1u && sphere_box(b, vc, 4u, groups_x, groups_y, &rows, &cols)) {
+        *col_begin = (cols & 0xffffu) * static_cast<uint32_t>(kTileW);
+        *col_end = std::min(vc.width, ((cols & 0xffffu) + (cols >> 16)) * static_cast<uint32_t>(kTileW));
+    }
+    return AEHIP_OK;
+}
+
 int aehip_backend_stats(aehip_backend *b, aehip_stats *out) {
     if(!b || !out) return fail(AEHIP_E_INVALID, "aehip_backend_stats: null argument");
     AEHIP_CHECK(hipSetDevice(b->device));

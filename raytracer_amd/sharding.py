@@ -92,6 +92,8 @@ class BandGather:
         self.parts = None
         self.image = None
         self._row_source = None
+        # whether the destination receives the bands stacked and reorders rows (known to every rank)
+        self._stacked = not (self.even and not self.tiled and not always_collective)
         if self.rank == dst:
             self.image = torch.zeros((height, width), dtype=torch.int32, device=device)
             if self.even and not self.tiled and not always_collective:
@@ -118,6 +120,7 @@ class BandGather:
             self.locals = [self.image[: self.max_rows], self.image[: self.max_rows]]
             self.local = self.locals[0]
         self._pending = [None, None]
+        self._narrow = None             # set_columns(): per slot, the kept columns of the band behind a background pixel a row
         # per buffer: event after which the buffer may be rendered into again (an event is
         # re-recorded freely: a wait holds the record it saw)
         self._events = [torch.cuda.Event() for _ in range(2)] if self.on_gpu else None
@@ -137,6 +140,56 @@ class BandGather:
         self._rendered = [torch.cuda.Event() for _ in range(2)] if self._stream_ordered else None
         self._reorder_stream = torch.cuda.Stream(device=device) if (self.on_gpu and self._row_source is not None and self.collective
                                                                     and not self._stream_ordered) else None
+
+    # ------------------------------------------------------------------ fewer bytes on the wire
+
+    def set_columns(self, col_begin: int, col_end: int) -> bool:
+        """Every band pixel outside columns [col_begin, col_end) holds its row's background colour
+        (HipRaytracer.background_columns(); the same two numbers on every rank): from now on a rank
+        sends those columns and one background pixel a row, and the destination's row reorder writes
+        the background around them.  A peer's band crosses one xGMI link (about 50-75 GB/s one way):
+        at a fraction of a millisecond a frame the bytes on that link, not the GPUs, bound the
+        frame rate, and on the reference's scene the sphere's columns are 40 % of the frame's.
+        Returns whether the narrow form is in use ((0, width), or columns that save less than a
+        quarter, switch it off).  Call between frames (nothing submitted and not finished)."""
+        self._narrow = None
+        device = self.locals[0].device
+        width = self.width
+        col_begin, col_end = max(0, int(col_begin)), min(width, int(col_end))
+        kept = col_end - col_begin + 1
+        if not self.collective or not self._stacked or col_end <= col_begin or kept * 4 > width * 3:
+            return False
+        if os.environ.get("RAYTRACER_AMD_WHOLE_ROWS") == "1":       # (whole rows on the wire, for comparison)
+            return False
+        # a background pixel of each row: the first column if it is outside the kept ones, else the last
+        bg = 0 if col_begin > 0 else width - 1
+        self._col_index = torch.cat([torch.tensor([bg], dtype=torch.int64), torch.arange(col_begin, col_end, dtype=torch.int64)]).to(device)
+        self._narrow = [torch.zeros((self.max_rows, kept), dtype=torch.int32, device=device) for _ in range(2)]
+        if self.rank == self.dst:
+            self._nrecvs = [torch.zeros((self.world, self.max_rows, kept), dtype=torch.int32, device=device)
+                            for _ in range(2 if self.on_gpu else 1)]
+            self._nrecv_parts = [[recv[r] for r in range(self.world)] for recv in self._nrecvs]
+            self._nrecv_flat = [recv.view(-1) for recv in self._nrecvs]
+            # image pixel (y, x) comes from word _row_source[y] * kept + (x - col_begin + 1 inside the kept columns, 0 outside)
+            cols = torch.zeros(width, dtype=torch.int64)
+            cols[col_begin:col_end] = torch.arange(1, kept, dtype=torch.int64)
+            source = self._row_source.cpu().view(-1, 1) * kept + cols.view(1, -1)
+            self._elem_source = source.view(-1).to(torch.int32).to(device)
+            self._image_flat = self.image.view(-1)
+        return True
+
+    def _pack(self, slot: int) -> torch.Tensor:
+        """The tensor this rank contributes for `slot`: the band, or its kept columns behind a background pixel a row."""
+        if self._narrow is None:
+            return self.locals[slot]
+        return torch.index_select(self.locals[slot], 1, self._col_index, out=self._narrow[slot])
+
+    def _receive_parts(self, slot: int):
+        if self._narrow is not None:
+            return self._nrecv_parts[slot if len(self._nrecvs) > 1 else 0]
+        if self._row_source is not None and len(self._recvs) > 1:
+            return self._recv_parts[slot]
+        return self.parts
 
     # ------------------------------------------------------------------ blocking form
 
@@ -169,10 +222,7 @@ class BandGather:
             torch.cuda.set_stream(self._comm_stream)        # (set_stream twice: 1 us; the context manager: 7)
             try:
                 self._comm_stream.wait_event(self._rendered[slot])
-                parts = None
-                if self.rank == self.dst:
-                    parts = self._recv_parts[slot] if self._row_source is not None else self.parts
-                dist.gather(self.locals[slot], parts, dst=self.dst)
+                dist.gather(self._pack(slot), self._receive_parts(slot) if self.rank == self.dst else None, dst=self.dst)
                 self._assemble(slot)
                 self._free[slot] = self._events[slot]       # the band buffer (and this slot's receive buffer) may be reused
                 self._free[slot].record(self._comm_stream)
@@ -214,23 +264,22 @@ class BandGather:
                 self._free[slot].record()
 
     def _start(self, slot: int, async_op: bool):
-        src = self.locals[slot]
         if not self.collective:
             return None                 # rendered straight into the image
         parts = None
         if self.rank == self.dst:
-            parts = self.parts
-            if self._row_source is not None and len(self._recvs) > 1:
+            parts = self._receive_parts(slot)
+            if self._row_source is not None and len(self._recvs) > 1 and self._free[slot] is not None:
                 # this slot's receive buffer; its previous frame's rows were reordered before the
                 # event that also frees the slot's band buffer, which begin() made this stream wait for
-                parts = self._recv_parts[slot]
-                if self._free[slot] is not None:
-                    torch.cuda.current_stream().wait_event(self._free[slot])
-        return dist.gather(src, parts, dst=self.dst, async_op=async_op)
+                torch.cuda.current_stream().wait_event(self._free[slot])
+        return dist.gather(self._pack(slot), parts, dst=self.dst, async_op=async_op)
 
     def _assemble(self, slot: int = 0) -> torch.Tensor | None:
         if self.rank != self.dst:
             return None
-        if self._row_source is not None and self.collective:
+        if self._narrow is not None:
+            torch.index_select(self._nrecv_flat[slot if len(self._nrecvs) > 1 else 0], 0, self._elem_source, out=self._image_flat)
+        elif self._row_source is not None and self.collective:
             torch.index_select(self._recv_rows[slot if len(self._recvs) > 1 else 0], 0, self._row_source, out=self.image)
         return self.image

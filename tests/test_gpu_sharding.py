@@ -71,10 +71,11 @@ def test_frames_arrive_whole_and_in_order_with_frames_on_alternating_streams(sin
     assert bool((image == frames).all())
 
 
-@pytest.mark.parametrize("untimed", [False, True])
-def test_rendered_frames_through_the_two_stream_pipeline_equal_the_single_launch(single_rank_rccl, untimed):
+@pytest.mark.parametrize("untimed,columns", [(False, False), (True, False), (True, True)])
+def test_rendered_frames_through_the_two_stream_pipeline_equal_the_single_launch(single_rank_rccl, untimed, columns):
     """untimed: the benchmark's form of the loop -- the library records no timing events
-    (AEHIP_FLAG_NO_TIMING) and begin() / submit() are handed the stream instead of looking it up."""
+    (AEHIP_FLAG_NO_TIMING) and begin() / submit() are handed the stream instead of looking it up.
+    columns: only the columns the library reports as more than background are gathered."""
     import torch
 
     device = torch.device("cuda", 0)
@@ -83,6 +84,10 @@ def test_rendered_frames_through_the_two_stream_pipeline_equal_the_single_launch
     back = rt.HipRaytracer(None, device=0)
     flags = rt.FLAG_JITTER | (rt.FLAG_NO_TIMING if untimed else 0)
     assert back.setup(width, height, spp=16, max_depth=1, seed=3, flags=flags, pass_=rt.PASS_PATH, **g.band), back.last_error()
+    if columns:
+        c0, c1 = back.background_columns()
+        assert 0 < c0 < c1 < width and (c1 - c0) < width * 0.6
+        assert g.set_columns(c0, c1)
     streams = [torch.cuda.Stream(device=device) for _ in range(2)]
     for i in range(7):
         side = streams[i & 1]
@@ -97,3 +102,64 @@ def test_rendered_frames_through_the_two_stream_pipeline_equal_the_single_launch
     back.close()
     whole, _ = rt.render(width, height, spp=16, max_depth=1, seed=3, jitter=True)
     np.testing.assert_array_equal(image.cpu().numpy().view(np.uint32), whole)
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_outside_the_reported_columns_every_row_is_one_colour(case):
+    """aehip_backend_background_columns on the default scene and on random single-sphere views, both builds,
+    both passes, jittered or not, every sample walked or not: left of col_begin and from col_end on, every pixel
+    of a row equals the row's other background pixels, in the packed image and in the averaged colours."""
+    import torch
+
+    rng = np.random.default_rng(4400 + case)
+    s = None
+    cam = None
+    if case >= 3:
+        s = np.zeros(1, dtype=rt.SPHERE_DTYPE)
+        depth = float(rng.choice([-1.5, -3.0, -8.0, -30.0]))
+        s["center"][0] = (rng.uniform(-0.8, 0.8) * abs(depth), rng.uniform(-0.4, 0.4) * abs(depth), depth)
+        s["radius"] = float(rng.choice([0.2, 0.6, 1.0]) * rng.uniform(0.7, 1.3))
+        s["material"] = int(rng.choice([rt.MAT_NORMAL, rt.MAT_LAMBERT, rt.MAT_METAL]))
+        s["albedo"][0] = (0.7, 0.6, 0.5)
+        cam = (float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.2, 0.2)), float(rng.choice([1.0, 0.5, 2.0])))
+    width, height = [(512, 512), (1920, 1080), (640, 360), (401, 230)][case % 4]
+    found = 0
+    for fast in (False, True):
+        for pass_, spp, flags in ((rt.PASS_PRIMARY, 1, 0), (rt.PASS_PATH, 16, rt.FLAG_JITTER), (rt.PASS_PATH, 64, rt.FLAG_JITTER | rt.FLAG_WALK_ALL)):
+            back = rt.HipRaytracer(None, device=0)
+            kw = {} if s is None else dict(spheres=s)
+            if cam is not None:
+                kw["cam"] = cam
+            assert back.setup(width, height, spp=spp, max_depth=3, seed=case, flags=flags | (rt.FLAG_FAST if fast else 0), pass_=pass_, **kw), back.last_error()
+            c0, c1 = back.background_columns()
+            assert 0 <= c0 <= c1 <= width
+            argb = torch.zeros((height, width), dtype=torch.int32, device="cuda")
+            rgba = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
+            back.trace_device(argb.data_ptr(), rgba.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            back.close()
+            if (c0, c1) == (0, width):
+                continue
+            found += 1
+            bg = 0 if c0 > 0 else width - 1
+            outside = torch.cat([torch.arange(0, c0), torch.arange(c1, width)]).to("cuda")
+            assert bool((argb[:, outside] == argb[:, bg:bg + 1]).all())
+            assert bool((rgba[:, outside] == rgba[:, bg:bg + 1]).all())
+    if s is None:
+        assert found == 6       # the reference's scene has its box at every size
+
+
+def test_every_band_of_a_frame_reports_the_same_columns():
+    from raytracer_amd.sharding import tiled_band
+
+    whole = rt.HipRaytracer(None, device=0)
+    assert whole.setup(3840, 2160, spp=64, flags=rt.FLAG_JITTER | rt.FLAG_FAST, pass_=rt.PASS_PATH)
+    want = whole.background_columns()
+    whole.close()
+    assert want == (1152, 2688)         # the reference's sphere: 1,528 pixels across at 4K, centred
+    for world, rank in ((2, 1), (8, 0), (8, 7), (540, 0), (540, 539)):      # (one tile of 4 rows a rank: sky only at either end)
+        for flags in (rt.FLAG_JITTER | rt.FLAG_FAST, 0):
+            back = rt.HipRaytracer(None, device=0)
+            assert back.setup(3840, 2160, spp=64, flags=flags, pass_=rt.PASS_PATH, **tiled_band(2160, world, rank, 4))
+            assert back.background_columns() == want
+            back.close()

@@ -133,3 +133,64 @@ def test_single_rank_renders_straight_into_the_image():
     assert image is g.image and bool((image == 3).all())
     g.local.fill_(7)
     assert bool((g.gather() == 7).all())
+
+
+# ------------------------------------------------------------------ kept columns (fewer bytes on the wire)
+
+def _columns_with_content(full):
+    """Columns outside of which every row of `full` is one value (what the library derives from the scene's geometry)."""
+    differs = (full != full[:, :1]).any(axis=0) | (full != full[:, -1:]).any(axis=0)
+    xs = np.flatnonzero(differs)
+    return (int(xs[0]), int(xs[-1]) + 1) if len(xs) else (0, 0)
+
+
+def _worker_columns(rank, world, port, width, height, out_path, overlapped, synthetic):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = BandGather(width, height, torch.device("cpu"))
+        if synthetic:
+            # a row gradient with a block of other values against the left edge: the background pixel is the row's last
+            full = np.repeat(np.arange(height, dtype=np.uint32)[:, None] * 3 + 7, width, axis=1)
+            full[height // 4: height // 2, : width // 3] = np.arange(width // 3, dtype=np.uint32)[None, :] + 1000
+        else:
+            full = oracle.trace_primary(width, height)
+        c0, c1 = _columns_with_content(full)
+        narrow = g.set_columns(c0, c1)
+        assert narrow == ((c1 - c0 + 1) * 4 <= width * 3)
+        band = torch.from_numpy(np.ascontiguousarray(full[band_image_rows(g.band)]).view(np.int32))
+        if overlapped:
+            for i in range(5):
+                buf = g.begin(i)
+                buf[: g.rows].copy_(band if i == 4 else torch.full_like(band, i + 1))
+                g.submit(i)
+            image = g.finish()
+        else:
+            g.local[: g.rows].copy_(band)
+            image = g.gather()
+        if rank == 0:
+            assert np.array_equal(image.numpy().view(np.uint32), full)
+            # switching the narrow form off again gathers whole rows as before
+            assert not g.set_columns(0, width)
+        else:
+            g.set_columns(0, width)
+        g.local[: g.rows].copy_(band)
+        image = g.gather()
+        if rank == 0:
+            np.save(out_path, image.numpy().view(np.uint32))
+            np.save(out_path + ".want.npy", full)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,size,overlapped,synthetic", [(2, (128, 72), False, False), (3, (100, 200), True, False),
+                                                             (4, (512, 64), True, False), (2, (96, 40), False, True),
+                                                             (3, (96, 41), True, True)])
+def test_gather_of_kept_columns_rebuilds_the_image(tmp_path, world, size, overlapped, synthetic):
+    """BandGather.set_columns: ranks send the columns that hold more than background and one background pixel a row;
+    the destination writes the background around them.  Both forms of the gather, a block against the frame's left
+    edge (background taken from the last column), and back to whole rows."""
+    width, height = size
+    out = str(tmp_path / "image.npy")
+    mp.spawn(_worker_columns, args=(world, free_port(), width, height, out, overlapped, synthetic), nprocs=world, join=True)
+    assert np.array_equal(np.load(out), np.load(out + ".want.npy"))

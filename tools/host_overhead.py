@@ -37,6 +37,8 @@ def main():
     back = rt.HipRaytracer(None, device=0)
     # --timed: the library's own timing events around every launch, as callers without AEHIP_FLAG_NO_TIMING get them
     assert back.setup(W, 270, spp=1, max_depth=1, seed=1, flags=rt.FLAG_FAST | (0 if a.timed else rt.FLAG_NO_TIMING), pass_=rt.PASS_PATH)
+    if not a.timed:
+        g.set_columns(*back.background_columns())       # bench.py's form: the sphere's columns and a background pixel a row
     sides = [side, torch.cuda.Stream(device=device)]
     handles = [s.cuda_stream for s in sides]
 
