@@ -31,7 +31,9 @@ The line also carries
                 and without path regeneration.
 
 With several ranks consecutive frames go to two streams in turn and the gather of a frame runs
-beside the next frame's rendering (raytracer_amd/sharding.py).  Rehearsals on a one-GPU box:
+beside the next frame's rendering (raytracer_amd/sharding.py); a rank sends the columns that hold
+more than the row's background and one background pixel a row, rank 0 rebuilds whole rows ("gather"
+in the line names the columns and the bytes a peer sends a frame).  Rehearsals on a one-GPU box:
 BENCH_FORCE_COLLECTIVE=1 runs that loop with a one-rank RCCL group; BENCH_SHARE_GPUS=1 under
 torch.distributed.run lets several ranks share the GPU, with gloo in RCCL's place.
 """

@@ -68,6 +68,9 @@ class BandGather:
     worth 2 % of a whole 4K frame and 8-15 % of an eighth of one.  A buffer is handed out again
     only after the gather that read it, wherever that gather was waited for.
 
+    `set_columns(c0, c1)` narrows what is sent to the columns that hold more than the row's
+    background (see there); the image on dst is whole either way.
+
     `band` holds the aehip_params fields of this rank's band (pass as **band to setup()).
     `always_collective` runs the collective and the stacked-bands path even for a single rank
     (tests of the protocol on one GPU)."""
@@ -121,6 +124,7 @@ class BandGather:
             self.local = self.locals[0]
         self._pending = [None, None]
         self._narrow = None             # set_columns(): per slot, the kept columns of the band behind a background pixel a row
+        self._columns = None
         # per buffer: event after which the buffer may be rendered into again (an event is
         # re-recorded freely: a wait holds the record it saw)
         self._events = [torch.cuda.Event() for _ in range(2)] if self.on_gpu else None
@@ -152,10 +156,13 @@ class BandGather:
         frame rate, and on the reference's scene the sphere's columns are 40 % of the frame's.
         Returns whether the narrow form is in use ((0, width), or columns that save less than a
         quarter, switch it off).  Call between frames (nothing submitted and not finished)."""
-        self._narrow = None
-        device = self.locals[0].device
         width = self.width
         col_begin, col_end = max(0, int(col_begin)), min(width, int(col_end))
+        if self._narrow is not None and self._columns == (col_begin, col_end):
+            return True                 # as it is: the buffers and the element map stay
+        self._narrow = None
+        self._columns = (col_begin, col_end)
+        device = self.locals[0].device
         kept = col_end - col_begin + 1
         if not self.collective or not self._stacked or col_end <= col_begin or kept * 4 > width * 3:
             return False
