@@ -189,6 +189,18 @@ int aehip_backend_stats(aehip_backend *backend, aehip_stats *out);
  * counterpart in the reference, whose frame never leaves one address space. */
 int aehip_backend_background_columns(aehip_backend *backend, uint32_t *col_begin, uint32_t *col_end);
 
+/* The two ends of moving a band's kept columns (no counterpart in the reference either; device
+ * pointers, asynchronous on `hip_stream`, on the current device).
+ * pack:   packed row r = { band[r][bg_col], band[r][col_begin .. col_end) }, rows of
+ *         col_end - col_begin + 1 words; bg_col is a column outside [col_begin, col_end).
+ * expand: image row y (height rows of width words) from packed row row_source[y] (64-bit indices
+ *         into the packed rows of every band, stacked as they were received): its own words
+ *         inside [col_begin, col_end), the row's background word outside. */
+int aehip_band_pack_columns(const uint32_t *band_dev, uint32_t rows, uint32_t width, uint32_t col_begin, uint32_t col_end,
+                            uint32_t bg_col, uint32_t *packed_dev, void *hip_stream);
+int aehip_band_expand_columns(const uint32_t *packed_dev, const long long *row_source_dev, uint32_t height, uint32_t width,
+                              uint32_t col_begin, uint32_t col_end, uint32_t *image_dev, void *hip_stream);
+
 /* One frame on `n_devices` GPUs of this node, driven from the calling thread; the multi-GPU form
  * of setup() + trace() (src/raytracer.h:25-26) for a host program that is one process, as the
  * reference is (src/main.cpp:11-25).  The rows params->row_begin .. +row_count (0 = all) are cut

@@ -88,6 +88,8 @@ EXPORTS = (
     "aehip_backend_trace_device_static",
     "aehip_backend_stats",
     "aehip_backend_background_columns",
+    "aehip_band_pack_columns",
+    "aehip_band_expand_columns",
     "aehip_trace_frame",
     "aehip_frame_band",
 )
@@ -130,6 +132,9 @@ def load() -> ctypes.CDLL:
         L.aehip_backend_trace_device_static.argtypes = [vp, vp, vp, vp]
         L.aehip_backend_stats.argtypes = [vp, ctypes.POINTER(AehipStats)]
         L.aehip_backend_background_columns.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+        u32 = ctypes.c_uint32
+        L.aehip_band_pack_columns.argtypes = [vp, u32, u32, u32, u32, u32, vp, vp]
+        L.aehip_band_expand_columns.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp]
         L.aehip_trace_frame.argtypes = [ctypes.c_int, ctypes.POINTER(AehipScene), ctypes.POINTER(AehipParams), vp,
                                         ctypes.POINTER(AehipStats)]
         L.aehip_frame_band.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int] + [ctypes.POINTER(ctypes.c_uint32)] * 3

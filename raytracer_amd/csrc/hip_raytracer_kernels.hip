@@ -3667,6 +3667,76 @@ extern "C" int aehip_wave_timeline(unsigned long long *out, unsigned int capacit
 }
 #endif
 
+// ------------------------------------------------------------------------------------------
+// bands between GPUs: the kept columns of a band behind one background pixel a row, and back
+// ------------------------------------------------------------------------------------------
+
+namespace {
+
+// out row r = { band[r][bg_col], band[r][col_begin .. col_end) }: one thread a word
+__global__ __launch_bounds__(256) void pack_columns_kernel(const uint32_t *__restrict__ band, uint32_t rows, uint32_t width,
+                                                           uint32_t col_begin, uint32_t kept, uint32_t bg_col, uint32_t *__restrict__ out) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x, r = blockIdx.y;
+    if(k >= kept || r >= rows) return;
+    const uint32_t x = k == 0u ? bg_col : col_begin + k - 1u;
+    out[static_cast<size_t>(r) * kept + k] = band[static_cast<size_t>(r) * width + x];
+}
+
+// image row y from packed row row_source[y]: the row's own words inside [col_begin, col_end), its
+// background word outside; a thread writes four pixels (one 16-byte store where the width allows)
+template <bool VEC4>
+__global__ __launch_bounds__(256) void expand_columns_kernel(const uint32_t *__restrict__ packed, const long long *__restrict__ row_source,
+                                                             uint32_t height, uint32_t width, uint32_t col_begin, uint32_t col_end,
+                                                             uint32_t kept, uint32_t *__restrict__ image) {
+    const uint32_t x0 = (blockIdx.x * 256u + threadIdx.x) * 4u, y = blockIdx.y;
+    if(x0 >= width || y >= height) return;
+    const uint32_t *src = packed + static_cast<size_t>(row_source[y]) * kept;
+    uint32_t w[4];
+#pragma unroll
+    for(uint32_t i = 0; i < 4u; i++) {
+        const uint32_t x = x0 + i;
+        w[i] = (x >= col_begin && x < col_end) ? src[1u + x - col_begin] : src[0];
+    }
+    uint32_t *dst = image + static_cast<size_t>(y) * width + x0;
+    if constexpr(VEC4) {
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+#pragma unroll
+        for(uint32_t i = 0; i < 4u; i++)
+            if(x0 + i < width) dst[i] = w[i];
+    }
+}
+
+}  // namespace
+
+extern "C" int aehip_band_pack_columns(const uint32_t *band_dev, uint32_t rows, uint32_t width, uint32_t col_begin, uint32_t col_end,
+                                       uint32_t bg_col, uint32_t *packed_dev, void *hip_stream) {
+    if(!band_dev || !packed_dev) return fail(AEHIP_E_INVALID, "aehip_band_pack_columns: null buffer");
+    if(rows == 0 || rows > 65535u || width == 0 || !(col_begin < col_end) || col_end > width || bg_col >= width)
+        return fail(AEHIP_E_INVALID, "aehip_band_pack_columns: %u rows of %u, columns %u..%u, background column %u", rows, width, col_begin, col_end, bg_col);
+    const uint32_t kept = col_end - col_begin + 1u;
+    hipLaunchKernelGGL(pack_columns_kernel, dim3((kept + 255u) / 256u, rows), dim3(256), 0, static_cast<hipStream_t>(hip_stream), band_dev, rows,
+                       width, col_begin, kept, bg_col, packed_dev);
+    AEHIP_CHECK(hipGetLastError());
+    return AEHIP_OK;
+}
+
+extern "C" int aehip_band_expand_columns(const uint32_t *packed_dev, const long long *row_source_dev, uint32_t height, uint32_t width,
+                                         uint32_t col_begin, uint32_t col_end, uint32_t *image_dev, void *hip_stream) {
+    if(!packed_dev || !row_source_dev || !image_dev) return fail(AEHIP_E_INVALID, "aehip_band_expand_columns: null buffer");
+    if(height == 0 || height > 65535u || width == 0 || !(col_begin < col_end) || col_end > width)
+        return fail(AEHIP_E_INVALID, "aehip_band_expand_columns: %u rows of %u, columns %u..%u", height, width, col_begin, col_end);
+    const uint32_t kept = col_end - col_begin + 1u;
+    const dim3 grid(((width + 3u) / 4u + 255u) / 256u, height);
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if(width % 4u == 0 && reinterpret_cast<uintptr_t>(image_dev) % 16u == 0)
+        hipLaunchKernelGGL(expand_columns_kernel<true>, grid, dim3(256), 0, stream, packed_dev, row_source_dev, height, width, col_begin, col_end, kept, image_dev);
+    else
+        hipLaunchKernelGGL(expand_columns_kernel<false>, grid, dim3(256), 0, stream, packed_dev, row_source_dev, height, width, col_begin, col_end, kept, image_dev);
+    AEHIP_CHECK(hipGetLastError());
+    return AEHIP_OK;
+}
+
 extern "C" int aehip_frame_band(uint32_t row_count, uint32_t tile_rows, int n_bands, int band, uint32_t *first_row,
                                 uint32_t *rows, uint32_t *rows_before) {
     if(n_bands < 1 || band < 0 || band >= n_bands || !first_row || !rows || !rows_before) return fail(AEHIP_E_INVALID, "aehip_frame_band: bad argument");

@@ -125,6 +125,9 @@ class BandGather:
         self._pending = [None, None]
         self._narrow = None             # set_columns(): per slot, the kept columns of the band behind a background pixel a row
         self._columns = None
+        self._handle = None             # inside submit(): the communication stream's hipStream_t
+        # on a GPU the library's kernels pack and expand (RAYTRACER_AMD_TORCH_COLUMNS=1: torch's gathers, for comparison)
+        self._use_lib = self.on_gpu and os.environ.get("RAYTRACER_AMD_TORCH_COLUMNS") != "1"
         # per buffer: event after which the buffer may be rendered into again (an event is
         # re-recorded freely: a wait holds the record it saw)
         self._events = [torch.cuda.Event() for _ in range(2)] if self.on_gpu else None
@@ -141,6 +144,7 @@ class BandGather:
         self._stream_ordered = bool(self.on_gpu and self.collective and dist.is_initialized() and dist.get_backend() == "nccl"
                                     and os.environ.get("RAYTRACER_AMD_ASYNC_GATHER") != "1")       # (1: the asynchronous form, for comparison)
         self._comm_stream = torch.cuda.Stream(device=device) if self._stream_ordered else None
+        self._comm_handle = self._comm_stream.cuda_stream if self._stream_ordered else None
         self._rendered = [torch.cuda.Event() for _ in range(2)] if self._stream_ordered else None
         self._reorder_stream = torch.cuda.Stream(device=device) if (self.on_gpu and self._row_source is not None and self.collective
                                                                     and not self._stream_ordered) else None
@@ -177,18 +181,36 @@ class BandGather:
                             for _ in range(2 if self.on_gpu else 1)]
             self._nrecv_parts = [[recv[r] for r in range(self.world)] for recv in self._nrecvs]
             self._nrecv_flat = [recv.view(-1) for recv in self._nrecvs]
-            # image pixel (y, x) comes from word _row_source[y] * kept + (x - col_begin + 1 inside the kept columns, 0 outside)
-            cols = torch.zeros(width, dtype=torch.int64)
-            cols[col_begin:col_end] = torch.arange(1, kept, dtype=torch.int64)
-            source = self._row_source.cpu().view(-1, 1) * kept + cols.view(1, -1)
-            self._elem_source = source.view(-1).to(torch.int32).to(device)
-            self._image_flat = self.image.view(-1)
+            if not self._use_lib:
+                # image pixel (y, x) comes from word _row_source[y] * kept + (x - col_begin + 1 inside the kept columns, 0 outside)
+                # (on a GPU the library's expand kernel works this out per pixel: a 4K frame's map is 33 MB to read a frame,
+                # and torch's gather through it took 68 us where the kernel takes a fraction of that)
+                cols = torch.zeros(width, dtype=torch.int64)
+                cols[col_begin:col_end] = torch.arange(1, kept, dtype=torch.int64)
+                source = self._row_source.cpu().view(-1, 1) * kept + cols.view(1, -1)
+                self._elem_source = source.view(-1).to(torch.int32).to(device)
+                self._image_flat = self.image.view(-1)
+        self._bg_col = bg
+        if self._use_lib:
+            import raytracer_amd
+            self._lib = raytracer_amd.load()
         return True
+
+    def _stream_handle(self) -> int:
+        """hipStream_t of the stream the gather's own kernels go to: the communication stream inside submit(), else the current one."""
+        return self._handle if self._handle is not None else torch.cuda.current_stream().cuda_stream
 
     def _pack(self, slot: int) -> torch.Tensor:
         """The tensor this rank contributes for `slot`: the band, or its kept columns behind a background pixel a row."""
         if self._narrow is None:
             return self.locals[slot]
+        if self._use_lib:
+            c0, c1 = self._columns
+            rc = self._lib.aehip_band_pack_columns(self.locals[slot].data_ptr(), self.max_rows, self.width, c0, c1, self._bg_col,
+                                                   self._narrow[slot].data_ptr(), self._stream_handle())
+            if rc != 0:
+                raise RuntimeError(f"aehip_band_pack_columns failed ({rc}): {self._lib.aehip_last_error().decode()}")
+            return self._narrow[slot]
         return torch.index_select(self.locals[slot], 1, self._col_index, out=self._narrow[slot])
 
     def _receive_parts(self, slot: int):
@@ -227,6 +249,7 @@ class BandGather:
             render_stream = stream if stream is not None else torch.cuda.current_stream()
             self._rendered[slot].record(render_stream)
             torch.cuda.set_stream(self._comm_stream)        # (set_stream twice: 1 us; the context manager: 7)
+            self._handle = self._comm_handle
             try:
                 self._comm_stream.wait_event(self._rendered[slot])
                 dist.gather(self._pack(slot), self._receive_parts(slot) if self.rank == self.dst else None, dst=self.dst)
@@ -234,6 +257,7 @@ class BandGather:
                 self._free[slot] = self._events[slot]       # the band buffer (and this slot's receive buffer) may be reused
                 self._free[slot].record(self._comm_stream)
             finally:
+                self._handle = None
                 torch.cuda.set_stream(render_stream)
             return
         self._complete(slot ^ 1)
@@ -285,7 +309,13 @@ class BandGather:
     def _assemble(self, slot: int = 0) -> torch.Tensor | None:
         if self.rank != self.dst:
             return None
-        if self._narrow is not None:
+        if self._narrow is not None and self._use_lib:
+            c0, c1 = self._columns
+            rc = self._lib.aehip_band_expand_columns(self._nrecvs[slot if len(self._nrecvs) > 1 else 0].data_ptr(), self._row_source.data_ptr(),
+                                                     self.height, self.width, c0, c1, self.image.data_ptr(), self._stream_handle())
+            if rc != 0:
+                raise RuntimeError(f"aehip_band_expand_columns failed ({rc}): {self._lib.aehip_last_error().decode()}")
+        elif self._narrow is not None:
             torch.index_select(self._nrecv_flat[slot if len(self._nrecvs) > 1 else 0], 0, self._elem_source, out=self._image_flat)
         elif self._row_source is not None and self.collective:
             torch.index_select(self._recv_rows[slot if len(self._recvs) > 1 else 0], 0, self._row_source, out=self.image)

@@ -163,3 +163,31 @@ def test_every_band_of_a_frame_reports_the_same_columns():
             assert back.setup(3840, 2160, spp=64, flags=flags, pass_=rt.PASS_PATH, **tiled_band(2160, world, rank, 4))
             assert back.background_columns() == want
             back.close()
+
+
+@pytest.mark.parametrize("shape", [(64, 3840, 1152, 2688), (37, 401, 0, 130), (9, 258, 100, 258), (5, 17, 3, 4), (270, 1922, 16, 1900)])
+def test_pack_and_expand_kernels_against_their_definition(shape):
+    """aehip_band_pack_columns / aehip_band_expand_columns on random words: kept columns at either edge, widths
+    that are not multiples of four (scalar stores), rows taken in a shuffled order."""
+    import torch
+
+    rows, width, c0, c1 = shape
+    lib = rt.load()
+    gen = torch.Generator(device="cpu").manual_seed(rows * 7919 + width)
+    band = torch.randint(-2**31, 2**31 - 1, (rows, width), dtype=torch.int32, generator=gen).cuda()
+    bg = 0 if c0 > 0 else width - 1
+    kept = c1 - c0 + 1
+    packed = torch.zeros((rows, kept), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    assert lib.aehip_band_pack_columns(band.data_ptr(), rows, width, c0, c1, bg, packed.data_ptr(), stream) == 0
+    want = torch.cat([band[:, bg:bg + 1], band[:, c0:c1]], dim=1)
+    assert torch.equal(packed, want)
+    order = torch.randperm(rows, generator=gen).cuda()
+    image = torch.zeros((rows, width), dtype=torch.int32, device="cuda")
+    assert lib.aehip_band_expand_columns(packed.data_ptr(), order.data_ptr(), rows, width, c0, c1, image.data_ptr(), stream) == 0
+    torch.cuda.synchronize()
+    rebuilt = band[order][:, bg:bg + 1].expand(rows, width).clone()
+    rebuilt[:, c0:c1] = band[order][:, c0:c1]
+    assert torch.equal(image, rebuilt)
+    assert lib.aehip_band_pack_columns(band.data_ptr(), rows, width, c1, c0, bg, packed.data_ptr(), stream) == -2
+    assert lib.aehip_band_expand_columns(None, order.data_ptr(), rows, width, c0, c1, image.data_ptr(), stream) == -2
