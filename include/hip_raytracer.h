@@ -125,6 +125,13 @@ typedef struct aehip_stats {
                                is the fraction of lanes doing useful work in the bounce loop
                                (only with AEHIP_FLAG_COUNT_RAYS)                            */
     uint32_t vgprs, sgprs, lds_bytes, reserved;   /* resource use of the kernel last launched */
+    uint64_t samples_walked; /* camera samples of the last trace that went through a sample loop.  The
+                               single-sphere camera pass decides pixels whose samples all miss from
+                               bounds over the pixel's sample positions and never walks them: this is
+                               spp x the pixels it did walk, counted on the device at set-up with the
+                               kernels' own classification (AEHIP_FLAG_WALK_ALL: every pixel).  Every
+                               other pass walks every sample (= paths).  `rays` keeps counting one
+                               segment per sample of the image, walked or decided.              */
 } aehip_stats;
 
 typedef struct aehip_backend aehip_backend;
@@ -171,7 +178,12 @@ int aehip_backend_trace_device(aehip_backend *backend, uint32_t *argb_dev, float
  * what must start at zero); every call on a GPU shares that GPU's array, so calls that overlap
  * on one GPU race -- issue them on one stream, or wait for one before starting the next.
  * Passes that use no scratch (the reference's pass, the camera pass, the per-lane path pass
- * without AEHIP_FLAG_COUNT_RAYS) run exactly as through aehip_backend_trace_device. */
+ * without AEHIP_FLAG_COUNT_RAYS) run exactly as through aehip_backend_trace_device.
+ * Under stream capture (hip_stream is capturing into a HIP graph): the request must carry
+ * AEHIP_FLAG_NO_TIMING (timing events cannot be read back from a graph; AEHIP_E_INVALID otherwise),
+ * and the call records nothing but kernel and memset nodes -- the events that order scratch users
+ * outside capture are left alone, so replays of the graph are ordered by the streams they are
+ * launched on and must not overlap other calls that use the scratch on that GPU. */
 #define AEHIP_STATIC_SCRATCH_BYTES (64u << 20)
 int aehip_backend_trace_device_static(aehip_backend *backend, uint32_t *argb_dev, float *rgba_dev, void *hip_stream);
 
@@ -194,12 +206,15 @@ int aehip_backend_background_columns(aehip_backend *backend, uint32_t *col_begin
  * pack:   packed row r = { band[r][bg_col], band[r][col_begin .. col_end) }, rows of
  *         col_end - col_begin + 1 words; bg_col is a column outside [col_begin, col_end).
  * expand: image row y (height rows of width words) from packed row row_source[y] (64-bit indices
- *         into the packed rows of every band, stacked as they were received): its own words
- *         inside [col_begin, col_end), the row's background word outside. */
+ *         into the `packed_rows` packed rows of every band, stacked as they were received): its own
+ *         words inside [col_begin, col_end), the row's background word outside.  An index outside
+ *         [0, packed_rows) leaves its image row unwritten (no read happens through it).
+ * Both launch on the device that is current in the calling thread; the buffers and the stream must
+ * belong to it. */
 int aehip_band_pack_columns(const uint32_t *band_dev, uint32_t rows, uint32_t width, uint32_t col_begin, uint32_t col_end,
                             uint32_t bg_col, uint32_t *packed_dev, void *hip_stream);
-int aehip_band_expand_columns(const uint32_t *packed_dev, const long long *row_source_dev, uint32_t height, uint32_t width,
-                              uint32_t col_begin, uint32_t col_end, uint32_t *image_dev, void *hip_stream);
+int aehip_band_expand_columns(const uint32_t *packed_dev, uint64_t packed_rows, const long long *row_source_dev, uint32_t height,
+                              uint32_t width, uint32_t col_begin, uint32_t col_end, uint32_t *image_dev, void *hip_stream);
 
 /* One frame on `n_devices` GPUs of this node, driven from the calling thread; the multi-GPU form
  * of setup() + trace() (src/raytracer.h:25-26) for a host program that is one process, as the

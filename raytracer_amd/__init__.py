@@ -71,6 +71,7 @@ class AehipStats(ctypes.Structure):
         ("sgprs", ctypes.c_uint32),
         ("lds_bytes", ctypes.c_uint32),
         ("reserved", ctypes.c_uint32),
+        ("samples_walked", ctypes.c_uint64),
     ]
 
 
@@ -134,7 +135,7 @@ def load() -> ctypes.CDLL:
         L.aehip_backend_background_columns.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
         u32 = ctypes.c_uint32
         L.aehip_band_pack_columns.argtypes = [vp, u32, u32, u32, u32, u32, vp, vp]
-        L.aehip_band_expand_columns.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp]
+        L.aehip_band_expand_columns.argtypes = [vp, ctypes.c_uint64, vp, u32, u32, u32, u32, vp, vp]
         L.aehip_trace_frame.argtypes = [ctypes.c_int, ctypes.POINTER(AehipScene), ctypes.POINTER(AehipParams), vp,
                                         ctypes.POINTER(AehipStats)]
         L.aehip_frame_band.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int] + [ctypes.POINTER(ctypes.c_uint32)] * 3

@@ -1630,6 +1630,31 @@ __global__ __launch_bounds__(256) void ring_pixels_kernel(view_consts vc, camera
     }
 }
 
+// Pixels of the band that the single-sphere camera pass walks through a sample loop: all but those
+// camera_body culls from the same classification (every sample misses; fast build: also a sphere
+// that only the far side of the camera faces).  Listed pixels are walked, in the reference's
+// arithmetic.  One atomic a wave.
+__global__ __launch_bounds__(256) void walked_pixels_kernel(view_consts vc, camera_consts cc, uint32_t fast, uint32_t *__restrict__ count) {
+    // a few hundred workgroups stride over the band: atomics on one word go through one at a time, so one a workgroup
+    __shared__ uint32_t s_count;
+    if(threadIdx.x == 0u) s_count = 0u;
+    __syncthreads();
+    const uint32_t pixels = vc.width * vc.row_count;
+    uint32_t mine = 0;
+    for(uint32_t gid = blockIdx.x * 256u + threadIdx.x; gid < pixels; gid += gridDim.x * 256u) {
+        const uint32_t row = gid / vc.width, x = gid - row * vc.width;
+        const pixel_class pc = classify_pixel(vc, cc, x, image_row(vc, row));
+        bool culled = !pc.may_hit;
+        if(fast != 0u && cc.near_root_only != 0u && pc.may_hit && pc.well_conditioned && !pc.faces_sphere) culled = true;
+        mine += culled ? 0u : 1u;
+    }
+#pragma unroll
+    for(int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if((threadIdx.x & 63u) == 0u && mine != 0u) atomicAdd(&s_count, mine);
+    __syncthreads();
+    if(threadIdx.x == 0u && s_count != 0u) atomicAdd(count, s_count);
+}
+
 #ifdef AEHIP_WAVE_TIMELINE
 // Measurement build (make timeline; tools/wave_timeline.py): every wave of the fast build's
 // single-sphere launch leaves its start and end on the constant-rate clock and whether it
@@ -2597,12 +2622,17 @@ static __device__ __align__(256) unsigned char g_static_scratch[kStaticScratchBy
 // up once per device with that device current; host code never uses the array's name as a pointer.
 constexpr int kMaxDevices = 64;
 unsigned char *g_static_scratch_ptr[kMaxDevices] = {};
+// End of the last launch that used the array on each GPU, whichever backend made it: two backends on one
+// GPU that call aehip_backend_trace_device_static on different streams are ordered by it.  Kept until the
+// process ends, like the array.
+hipEvent_t g_static_scratch_event[kMaxDevices] = {};
 
 hipError_t resolve_static_scratch(int device) {        // `device` must be current
     if(device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
     if(g_static_scratch_ptr[device]) return hipSuccess;
     void *ptr = nullptr;
-    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_static_scratch));
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_static_scratch));
+    if(e == hipSuccess && !g_static_scratch_event[device]) e = hipEventCreateWithFlags(&g_static_scratch_event[device], hipEventDisableTiming);
     if(e == hipSuccess) g_static_scratch_ptr[device] = static_cast<unsigned char *>(ptr);
     return e;
 }
@@ -2670,6 +2700,10 @@ struct aehip_backend {
     aehip_stats stats{};
     bool counts_known = false;               // the last launch's ray / lane-slot counts follow from its shape
     uint64_t known_rays = 0, known_lane_slots = 0;
+    uint64_t walked_pixels = 0;              // single-sphere camera pass: pixels of the band that go through a sample loop (set-up counts them)
+    bool culls_pixels = false;               // ... and whether that pass decides any pixel without walking it
+    const void *stream_func = nullptr;       // streamed pass: the tracing kernel set-up chose, and how many of its
+    int stream_groups_per_cu = 0;            //   workgroups a compute unit holds at once
 };
 
 namespace {
@@ -2816,17 +2850,63 @@ bool sphere_box(const aehip_backend *b, const view_consts &vc, uint32_t rows_per
     return true;
 }
 
+// Clears the ray counters and the unit queue.  A kernel rather than hipMemsetAsync: under stream capture
+// the memset nodes of these 8- and 16-byte clears did not take effect on replay (the counters came back
+// with the array's old contents), while kernel nodes replay as launched.
+__global__ __launch_bounds__(64) void clear_words_kernel(unsigned long long *__restrict__ words, uint32_t count) {
+    if(threadIdx.x < count) words[threadIdx.x] = 0ull;
+}
+
+// The tracing kernel of the streamed pass for this backend's request (decided by the build, the list's
+// length and set-up's estimate of what the list prefilter saves).
+const void *streamed_kernel(const aehip_backend *b) {
+    const bool exact = !(b->vc.flags & AEHIP_FLAG_FAST);
+    // the list prefilter (8 operations a sphere) pays where the screening value costs 12 (exact
+    // build; the fast build's 10 are not enough to cover the groups that pass) and few groups
+    // of four pass it in any lane (set-up's estimate)
+    const bool prefilter = exact && b->prefilter_pays;
+    if(b->vc.n_spheres >= kFirstHitsMinSpheres) {
+        if(exact) return prefilter ? reinterpret_cast<const void *>(path_stream_first_hits_kernel<true, true>) : reinterpret_cast<const void *>(path_stream_first_hits_kernel<true, false>);
+        return prefilter ? reinterpret_cast<const void *>(path_stream_first_hits_kernel<false, true>) : reinterpret_cast<const void *>(path_stream_first_hits_kernel<false, false>);
+    }
+    if(exact) return prefilter ? reinterpret_cast<const void *>(path_stream_kernel<true, true>) : reinterpret_cast<const void *>(path_stream_kernel<true, false>);
+    return prefilter ? reinterpret_cast<const void *>(path_stream_kernel<false, true>) : reinterpret_cast<const void *>(path_stream_kernel<false, false>);
+}
+
+// Is `stream` being captured into a HIP graph?  (false for the null stream and on any error: a stream that cannot be asked is not capturing)
+bool stream_is_capturing(hipStream_t stream) {
+    if(stream == nullptr) return false;
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    if(hipStreamIsCapturing(stream, &status) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return status != hipStreamCaptureStatusNone;
+}
+
 int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t stream, const stream_scratch &scratch) {
     const view_consts &vc = b->vc;
     // Launches of one backend share one scratch: a launch that uses it (the streamed pass, the ray
     // counters) is ordered after the last one that did, whatever streams the two were given.
+    // (Under stream capture the launch leaves events alone: a graph's replays are ordered by the streams
+    // they are launched on.)
     const bool uses_scratch = (vc.flags & AEHIP_FLAG_COUNT_RAYS) || takes_streamed_pass(b);
-    if(uses_scratch) AEHIP_CHECK(hipStreamWaitEvent(stream, b->ev_scratch, 0));
+    const bool capturing = stream_is_capturing(stream);
+    // the fixed array of aehip_backend_trace_device_static is shared by every backend on the GPU: its users are
+    // ordered by the GPU's event as well as by the backend's own
+    hipEvent_t shared_event = nullptr;
+    if(uses_scratch && b->device >= 0 && b->device < kMaxDevices && g_static_scratch_ptr[b->device] != nullptr &&
+       reinterpret_cast<unsigned char *>(scratch.counters) == g_static_scratch_ptr[b->device])
+        shared_event = g_static_scratch_event[b->device];
+    if(uses_scratch && !capturing) {
+        AEHIP_CHECK(hipStreamWaitEvent(stream, b->ev_scratch, 0));
+        if(shared_event) AEHIP_CHECK(hipStreamWaitEvent(stream, shared_event, 0));
+    }
     const bool exact = !(vc.flags & AEHIP_FLAG_FAST);
     float4 *rgba = reinterpret_cast<float4 *>(rgba_dev);
     const void *func = nullptr;
 
-    if(vc.flags & AEHIP_FLAG_COUNT_RAYS) AEHIP_CHECK(hipMemsetAsync(scratch.counters, 0, 2 * sizeof(unsigned long long), stream));
+    if(vc.flags & AEHIP_FLAG_COUNT_RAYS) hipLaunchKernelGGL(clear_words_kernel, dim3(1), dim3(64), 0, stream, scratch.counters, 2u);
     b->last_counters = scratch.counters;
     b->counts_known = false;
 
@@ -2949,22 +3029,12 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         if(takes_streamed_pass(b)) {
             // persistent waves: no more workgroups than the chip holds at once (a larger grid
             // would be just as correct -- late waves would find the queue empty); one launch
-            // pair per block of samples
-            int per_cu = 0;
+            // pair per block of samples.  The kernel and its residency are set-up's (streamed_kernel).
             const bool first_hits = vc.n_spheres >= kFirstHitsMinSpheres;
             const uint32_t deal_rounds = kDealRounds;
-            // the list prefilter (8 operations a sphere) pays where the screening value costs 12 (exact
-            // build; the fast build's 10 are not enough to cover the groups that pass) and few groups
-            // of four pass it in any lane (set-up's estimate)
-            const bool prefilter = exact && b->prefilter_pays;
-            if(first_hits) {
-                if(exact) func = prefilter ? reinterpret_cast<const void *>(path_stream_first_hits_kernel<true, true>) : reinterpret_cast<const void *>(path_stream_first_hits_kernel<true, false>);
-                else func = prefilter ? reinterpret_cast<const void *>(path_stream_first_hits_kernel<false, true>) : reinterpret_cast<const void *>(path_stream_first_hits_kernel<false, false>);
-            } else {
-                if(exact) func = prefilter ? reinterpret_cast<const void *>(path_stream_kernel<true, true>) : reinterpret_cast<const void *>(path_stream_kernel<true, false>);
-                else func = prefilter ? reinterpret_cast<const void *>(path_stream_kernel<false, true>) : reinterpret_cast<const void *>(path_stream_kernel<false, false>);
-            }
-            AEHIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, func, kBlock, 0));
+            func = b->stream_func;
+            const int per_cu = b->stream_groups_per_cu;
+            if(!func) return fail(AEHIP_E_INVALID, "streamed pass without a kernel (set-up did not choose one for this request)");
             const uint32_t strips = ((vc.width + kTileW - 1) / kTileW) * ((vc.row_count + 3u) / 4u);
             const uint32_t resident = static_cast<uint32_t>(per_cu > 0 ? per_cu : 1) * static_cast<uint32_t>(b->cu_count);
             const uint32_t nblocks = (vc.spp + AEHIP_SAMPLE_BLOCK - 1u) / AEHIP_SAMPLE_BLOCK;
@@ -2984,7 +3054,7 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
                     const uint32_t count = std::min(AEHIP_SAMPLE_BLOCK, vc.spp - begin);
                     const uint64_t units = static_cast<uint64_t>(win.count) * ((count + kChunkSamples - 1u) / kChunkSamples);
                     const uint32_t groups = static_cast<uint32_t>(std::min<uint64_t>(resident, (units + 3u) / 4u));
-                    AEHIP_CHECK(hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream));
+                    hipLaunchKernelGGL(clear_words_kernel, dim3(1), dim3(64), 0, stream, scratch.counters + 2, 1u);
                     if(first_hits) {
                         const dim3 first_grid(static_cast<uint32_t>((units + 3u) / 4u));
                         if(exact) hipLaunchKernelGGL(first_hit_kernel<true>, first_grid, dim3(kBlock), 0, stream, vc, b->d_geom, b->d_camera, b->d_sample_terms, scratch.radiance, begin, count, scratch.counters, win);
@@ -3013,10 +3083,14 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
 #undef AEHIP_LAUNCH_PATH
     }
     AEHIP_CHECK(hipGetLastError());
-    if(uses_scratch) AEHIP_CHECK(hipEventRecord(b->ev_scratch, stream));
+    if(uses_scratch && !capturing) {
+        AEHIP_CHECK(hipEventRecord(b->ev_scratch, stream));
+        if(shared_event) AEHIP_CHECK(hipEventRecord(shared_event, stream));
+    }
 
     // resource figures of the kernel just launched; queried once per kernel and backend, not per launch
-    if(func != b->attr_func) {
+    // (and not while a graph is being captured: the figures then stay those of the last launch outside capture)
+    if(func != b->attr_func && !capturing) {
         hipFuncAttributes attr;
         if(hipFuncGetAttributes(&attr, func) == hipSuccess) {
             b->stats.vgprs = static_cast<uint32_t>(attr.numRegs);
@@ -3345,7 +3419,12 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
         b->params = p;                  // takes_streamed_pass() reads the request
         const bool wanted = takes_streamed_pass(b);
         b->wants_streamed_pass = wanted;
+        b->stream_func = nullptr;
+        b->stream_groups_per_cu = 0;
         if(wanted) {
+            // the tracing kernel and its residency, here rather than per launch: a launch may be under stream capture
+            b->stream_func = streamed_kernel(b);
+            AEHIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b->stream_groups_per_cu, b->stream_func, kBlock, 0));
             const size_t strips = static_cast<size_t>((p.width + kTileW - 1) / kTileW) * ((p.row_count + 3u) / 4u);
             const size_t per_strip = scratch_bytes_per_strip(p.spp);
             const size_t window = std::min(strips, std::max<size_t>(1, kScratchBudget / per_strip));
@@ -3368,6 +3447,25 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
     if((p.flags & AEHIP_FLAG_FAST) && p.pass == AEHIP_PASS_PATH && single_sphere_camera_pass(b)) {
         const int rc = build_ring_list(b);
         if(rc != AEHIP_OK) return rc;
+    }
+
+    // single-sphere camera pass: the pixels that go through a sample loop (aehip_stats.samples_walked).  The
+    // pass classifies pixels in the fast build always and in the exact build where it screens with the folded
+    // ray (launch() hands it the table of all-miss sums only then), unless every sample is to be walked.
+    b->walked_pixels = static_cast<uint64_t>(p.width) * p.row_count;
+    b->culls_pixels = p.pass == AEHIP_PASS_PATH && single_sphere_camera_pass(b) && !(p.flags & AEHIP_FLAG_WALK_ALL) &&
+                      ((p.flags & AEHIP_FLAG_FAST) || (vc.flags & kFlagFoldScreen));
+    if(b->culls_pixels) {
+        uint32_t *d_count = reinterpret_cast<uint32_t *>(b->d_rays + 2);          // the streamed pass's queue word: idle during set-up
+        uint32_t count = 0;
+        AEHIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t), b->stream));
+        const uint64_t pixels = static_cast<uint64_t>(p.width) * p.row_count;
+        hipLaunchKernelGGL(walked_pixels_kernel, dim3(static_cast<uint32_t>(std::min<uint64_t>((pixels + 255u) / 256u, 2048u))), dim3(256), 0, b->stream, vc, b->cc,
+                           (p.flags & AEHIP_FLAG_FAST) ? 1u : 0u, d_count);
+        AEHIP_CHECK(hipGetLastError());
+        AEHIP_CHECK(hipMemcpyAsync(&count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+        AEHIP_CHECK(hipStreamSynchronize(b->stream));
+        b->walked_pixels = count;
     }
 
     // exact build, single-sphere camera pass: the value of the pixels whose samples all miss
@@ -3414,6 +3512,7 @@ int aehip_backend_trace_device(aehip_backend *b, uint32_t *argb_dev, float *rgba
     const bool own = hip_stream == nullptr;
     hipStream_t stream = own ? b->stream : static_cast<hipStream_t>(hip_stream);
     const bool timed = (b->vc.flags & AEHIP_FLAG_NO_TIMING) == 0u;
+    if(timed && stream_is_capturing(stream)) return fail(AEHIP_E_INVALID, "the stream is being captured: timing events cannot go into a graph, set AEHIP_FLAG_NO_TIMING");
     if(timed) AEHIP_CHECK(hipEventRecord(b->ev_begin, stream));
     const int rc = launch(b, argb_dev, rgba_dev, stream, own_scratch(b));
     if(rc != AEHIP_OK) return rc;
@@ -3447,6 +3546,7 @@ int aehip_backend_trace_device_static(aehip_backend *b, uint32_t *argb_dev, floa
     const bool own = hip_stream == nullptr;
     hipStream_t stream = own ? b->stream : static_cast<hipStream_t>(hip_stream);
     const bool timed = (b->vc.flags & AEHIP_FLAG_NO_TIMING) == 0u;
+    if(timed && stream_is_capturing(stream)) return fail(AEHIP_E_INVALID, "the stream is being captured: timing events cannot go into a graph, set AEHIP_FLAG_NO_TIMING");
     if(timed) AEHIP_CHECK(hipEventRecord(b->ev_begin, stream));
     const int rc = launch(b, argb_dev, rgba_dev, stream, sc);
     if(rc != AEHIP_OK) return rc;
@@ -3586,6 +3686,8 @@ int aehip_backend_stats(aehip_backend *b, aehip_stats *out) {
         b->stats.rays = 0;
         b->stats.lane_slots = 0;
     }
+    // samples that went through a sample loop: set-up's count for the pass that culls pixels (whole band), else every path
+    b->stats.samples_walked = b->culls_pixels ? b->walked_pixels * b->vc.spp : b->stats.paths;
     *out = b->stats;
     return AEHIP_OK;
 }
@@ -3613,6 +3715,16 @@ struct frame_state {
     std::vector<aehip_backend *> bands;      // one backend per logical device
     std::vector<ncclComm_t> comms;           // valid when the devices are distinct GPUs
     rccl_api rccl;
+    // gather of kept columns (device 0): the bands' packed rows stacked in band order, the frame in image
+    // order, and for every frame row the stacked row it comes from
+    uint32_t *d_stack = nullptr, *d_image = nullptr;
+    long long *d_row_source = nullptr;
+    size_t stack_capacity = 0, image_capacity = 0, row_source_capacity = 0;    // words, pixels, rows
+    uint64_t row_source_key = 0;             // (rows, tile height, bands) the row map was built for
+    std::vector<uint32_t *> d_packed;        // per band: its packed rows on its own device (peers only)
+    std::vector<size_t> packed_capacity;     // words
+    hipEvent_t ev_received = nullptr;        // device 0: the peers' rows have arrived
+    int device0 = 0;
 };
 frame_state g_frame;
 
@@ -3620,6 +3732,22 @@ void release_frame_state() {
     for(ncclComm_t c : g_frame.comms)
         if(c && g_frame.rccl.CommDestroy) (void)g_frame.rccl.CommDestroy(c);
     g_frame.comms.clear();
+    for(size_t i = 0; i < g_frame.d_packed.size(); i++) {
+        if(g_frame.d_packed[i] && i < g_frame.bands.size() && hipSetDevice(g_frame.bands[i]->device) == hipSuccess) (void)hipFree(g_frame.d_packed[i]);
+    }
+    g_frame.d_packed.clear();
+    g_frame.packed_capacity.clear();
+    if(!g_frame.bands.empty() && hipSetDevice(g_frame.device0) == hipSuccess) {
+        if(g_frame.d_stack) (void)hipFree(g_frame.d_stack);
+        if(g_frame.d_image) (void)hipFree(g_frame.d_image);
+        if(g_frame.d_row_source) (void)hipFree(g_frame.d_row_source);
+        if(g_frame.ev_received) (void)hipEventDestroy(g_frame.ev_received);
+    }
+    g_frame.d_stack = g_frame.d_image = nullptr;
+    g_frame.d_row_source = nullptr;
+    g_frame.stack_capacity = g_frame.image_capacity = g_frame.row_source_capacity = 0;
+    g_frame.row_source_key = 0;
+    g_frame.ev_received = nullptr;
     for(aehip_backend *b : g_frame.bands) aehip_backend_destroy(b);
     g_frame.bands.clear();
     if(g_frame.rccl.lib) dlclose(g_frame.rccl.lib);
@@ -3685,12 +3813,14 @@ __global__ __launch_bounds__(256) void pack_columns_kernel(const uint32_t *__res
 // image row y from packed row row_source[y]: the row's own words inside [col_begin, col_end), its
 // background word outside; a thread writes four pixels (one 16-byte store where the width allows)
 template <bool VEC4>
-__global__ __launch_bounds__(256) void expand_columns_kernel(const uint32_t *__restrict__ packed, const long long *__restrict__ row_source,
-                                                             uint32_t height, uint32_t width, uint32_t col_begin, uint32_t col_end,
-                                                             uint32_t kept, uint32_t *__restrict__ image) {
+__global__ __launch_bounds__(256) void expand_columns_kernel(const uint32_t *__restrict__ packed, unsigned long long packed_rows,
+                                                             const long long *__restrict__ row_source, uint32_t height, uint32_t width,
+                                                             uint32_t col_begin, uint32_t col_end, uint32_t kept, uint32_t *__restrict__ image) {
     const uint32_t x0 = (blockIdx.x * 256u + threadIdx.x) * 4u, y = blockIdx.y;
     if(x0 >= width || y >= height) return;
-    const uint32_t *src = packed + static_cast<size_t>(row_source[y]) * kept;
+    const long long source = row_source[y];
+    if(source < 0 || static_cast<unsigned long long>(source) >= packed_rows) return;       // a row no band holds: left as it is
+    const uint32_t *src = packed + static_cast<size_t>(source) * kept;
     uint32_t w[4];
 #pragma unroll
     for(uint32_t i = 0; i < 4u; i++) {
@@ -3714,6 +3844,8 @@ extern "C" int aehip_band_pack_columns(const uint32_t *band_dev, uint32_t rows, 
     if(!band_dev || !packed_dev) return fail(AEHIP_E_INVALID, "aehip_band_pack_columns: null buffer");
     if(rows == 0 || rows > 65535u || width == 0 || !(col_begin < col_end) || col_end > width || bg_col >= width)
         return fail(AEHIP_E_INVALID, "aehip_band_pack_columns: %u rows of %u, columns %u..%u, background column %u", rows, width, col_begin, col_end, bg_col);
+    if(bg_col >= col_begin && bg_col < col_end)
+        return fail(AEHIP_E_INVALID, "aehip_band_pack_columns: background column %u lies inside the kept columns %u..%u", bg_col, col_begin, col_end);
     const uint32_t kept = col_end - col_begin + 1u;
     hipLaunchKernelGGL(pack_columns_kernel, dim3((kept + 255u) / 256u, rows), dim3(256), 0, static_cast<hipStream_t>(hip_stream), band_dev, rows,
                        width, col_begin, kept, bg_col, packed_dev);
@@ -3721,18 +3853,19 @@ extern "C" int aehip_band_pack_columns(const uint32_t *band_dev, uint32_t rows, 
     return AEHIP_OK;
 }
 
-extern "C" int aehip_band_expand_columns(const uint32_t *packed_dev, const long long *row_source_dev, uint32_t height, uint32_t width,
-                                         uint32_t col_begin, uint32_t col_end, uint32_t *image_dev, void *hip_stream) {
+extern "C" int aehip_band_expand_columns(const uint32_t *packed_dev, uint64_t packed_rows, const long long *row_source_dev, uint32_t height,
+                                         uint32_t width, uint32_t col_begin, uint32_t col_end, uint32_t *image_dev, void *hip_stream) {
     if(!packed_dev || !row_source_dev || !image_dev) return fail(AEHIP_E_INVALID, "aehip_band_expand_columns: null buffer");
-    if(height == 0 || height > 65535u || width == 0 || !(col_begin < col_end) || col_end > width)
-        return fail(AEHIP_E_INVALID, "aehip_band_expand_columns: %u rows of %u, columns %u..%u", height, width, col_begin, col_end);
+    if(height == 0 || height > 65535u || width == 0 || !(col_begin < col_end) || col_end > width || packed_rows == 0)
+        return fail(AEHIP_E_INVALID, "aehip_band_expand_columns: %u rows of %u, columns %u..%u, %llu packed rows", height, width, col_begin, col_end,
+                    static_cast<unsigned long long>(packed_rows));
     const uint32_t kept = col_end - col_begin + 1u;
     const dim3 grid(((width + 3u) / 4u + 255u) / 256u, height);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     if(width % 4u == 0 && reinterpret_cast<uintptr_t>(image_dev) % 16u == 0)
-        hipLaunchKernelGGL(expand_columns_kernel<true>, grid, dim3(256), 0, stream, packed_dev, row_source_dev, height, width, col_begin, col_end, kept, image_dev);
+        hipLaunchKernelGGL(expand_columns_kernel<true>, grid, dim3(256), 0, stream, packed_dev, static_cast<unsigned long long>(packed_rows), row_source_dev, height, width, col_begin, col_end, kept, image_dev);
     else
-        hipLaunchKernelGGL(expand_columns_kernel<false>, grid, dim3(256), 0, stream, packed_dev, row_source_dev, height, width, col_begin, col_end, kept, image_dev);
+        hipLaunchKernelGGL(expand_columns_kernel<false>, grid, dim3(256), 0, stream, packed_dev, static_cast<unsigned long long>(packed_rows), row_source_dev, height, width, col_begin, col_end, kept, image_dev);
     AEHIP_CHECK(hipGetLastError());
     return AEHIP_OK;
 }
@@ -3845,6 +3978,7 @@ extern "C" int aehip_trace_frame(int n_devices, const aehip_scene *scene, const 
     // device 0 holds every band, densely, one after the other, and renders its own band straight
     // into place; peers render into band buffers of their own
     aehip_backend *b0 = g_frame.bands[0];
+    g_frame.device0 = b0->device;
     const size_t frame_pixels = static_cast<size_t>(frame.width) * frame.row_count;
     for(int i = 0; i < n; i++) {
         aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
@@ -3864,6 +3998,68 @@ extern "C" int aehip_trace_frame(int n_devices, const aehip_scene *scene, const 
         AEHIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&b0->h_staging), frame_pixels * sizeof(uint32_t), hipHostMallocDefault));
         b0->staging_capacity = frame_pixels;
     }
+    if(!g_frame.ev_received) AEHIP_CHECK(hipEventCreateWithFlags(&g_frame.ev_received, hipEventDisableTiming));
+
+    // What a peer sends.  Outside the columns aehip_backend_background_columns reports, every pixel of a
+    // band row holds the row's background: a peer packs those columns behind one background pixel a row
+    // (pack_columns_kernel), and device 0 rebuilds the frame's rows, in image order, from the stacked packed
+    // rows of all bands, its own included (expand_columns_kernel).  A peer's band crosses one xGMI link: on the
+    // reference's scene the kept columns are 40 % of a row.  Scenes for which no such columns are known
+    // (several shapes), or columns that save less than a quarter, go as whole rows, as before.
+    uint32_t col_begin = 0, col_end = frame.width;
+    if(n > 1) {
+        const int rc = aehip_backend_background_columns(b0, &col_begin, &col_end);
+        if(rc != AEHIP_OK) return rc;
+    }
+    const uint32_t kept = col_end - col_begin + 1u;
+    const bool narrow = n > 1 && col_end > col_begin && static_cast<uint64_t>(kept) * 4u <= static_cast<uint64_t>(frame.width) * 3u;
+    const uint32_t bg_col = col_begin > 0u ? 0u : frame.width - 1u;         // a column outside the kept ones
+    if(narrow) {
+        g_frame.d_packed.resize(static_cast<size_t>(n), nullptr);
+        g_frame.packed_capacity.resize(static_cast<size_t>(n), 0);
+        for(int i = 1; i < n; i++) {
+            aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
+            const size_t need = static_cast<size_t>(kept) * b->vc.row_count;
+            if(need > g_frame.packed_capacity[static_cast<size_t>(i)]) {
+                AEHIP_CHECK(hipSetDevice(b->device));
+                if(g_frame.d_packed[static_cast<size_t>(i)]) (void)hipFree(g_frame.d_packed[static_cast<size_t>(i)]);
+                g_frame.d_packed[static_cast<size_t>(i)] = nullptr; g_frame.packed_capacity[static_cast<size_t>(i)] = 0;
+                AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&g_frame.d_packed[static_cast<size_t>(i)]), need * sizeof(uint32_t)));
+                g_frame.packed_capacity[static_cast<size_t>(i)] = need;
+            }
+        }
+        AEHIP_CHECK(hipSetDevice(b0->device));
+        const size_t stack_words = static_cast<size_t>(kept) * frame.row_count;
+        if(stack_words > g_frame.stack_capacity) {
+            if(g_frame.d_stack) (void)hipFree(g_frame.d_stack);
+            g_frame.d_stack = nullptr; g_frame.stack_capacity = 0;
+            AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&g_frame.d_stack), stack_words * sizeof(uint32_t)));
+            g_frame.stack_capacity = stack_words;
+        }
+        if(frame_pixels > g_frame.image_capacity) {
+            if(g_frame.d_image) (void)hipFree(g_frame.d_image);
+            g_frame.d_image = nullptr; g_frame.image_capacity = 0;
+            AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&g_frame.d_image), frame_pixels * sizeof(uint32_t)));
+            g_frame.image_capacity = frame_pixels;
+        }
+        if(frame.row_count > g_frame.row_source_capacity) {
+            if(g_frame.d_row_source) (void)hipFree(g_frame.d_row_source);
+            g_frame.d_row_source = nullptr; g_frame.row_source_capacity = 0; g_frame.row_source_key = 0;
+            AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&g_frame.d_row_source), frame.row_count * sizeof(long long)));
+            g_frame.row_source_capacity = frame.row_count;
+        }
+        // frame row y is row (y / T) / n * T + y % T of band (y / T) % n; the map changes with the rows, the tile height or the bands only
+        const uint64_t key = (static_cast<uint64_t>(frame.row_count) << 32) ^ (static_cast<uint64_t>(T) << 8) ^ static_cast<uint64_t>(n);
+        if(key != g_frame.row_source_key) {
+            std::vector<long long> source(frame.row_count);
+            for(uint32_t y = 0; y < frame.row_count; y++) {
+                const uint32_t tile = y / T, band = tile % static_cast<uint32_t>(n);
+                source[y] = static_cast<long long>(offset[band]) + (tile / static_cast<uint32_t>(n)) * T + (y - tile * T);
+            }
+            AEHIP_CHECK(hipMemcpy(g_frame.d_row_source, source.data(), source.size() * sizeof(long long), hipMemcpyHostToDevice));
+            g_frame.row_source_key = key;
+        }
+    }
 
     // From the first launch on, an error must not return while other devices still work on buffers
     // a later call may free: wait for every band's stream, then report.
@@ -3872,6 +4068,7 @@ extern "C" int aehip_trace_frame(int n_devices, const aehip_scene *scene, const 
             aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
             if(hipSetDevice(b->device) == hipSuccess) (void)hipStreamSynchronize(b->stream);
         }
+        if(hipSetDevice(b0->device) == hipSuccess) (void)hipStreamSynchronize(b0->copy_stream);
         return rc;
     };
 #define AEHIP_FRAME_CHECK(expr)                                                                                     \
@@ -3885,7 +4082,7 @@ extern "C" int aehip_trace_frame(int n_devices, const aehip_scene *scene, const 
         if(r_ != ncclSuccess) return settle(fail(AEHIP_E_HIP, "%s failed: %s", #expr, (api).GetErrorString(r_)));   \
     } while(0)
 
-    // render: every device at once, each on its own stream
+    // render: every device at once, each on its own stream; a peer packs its kept columns behind its render
     for(int i = 0; i < n; i++) {
         aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
         AEHIP_FRAME_CHECK(hipSetDevice(b->device));
@@ -3893,53 +4090,83 @@ extern "C" int aehip_trace_frame(int n_devices, const aehip_scene *scene, const 
         const int rc = launch(b, b->d_argb, nullptr, b->stream, own_scratch(b));
         if(rc != AEHIP_OK) return settle(rc);
         AEHIP_FRAME_CHECK(hipEventRecord(b->ev_end, b->stream));
+        if(narrow && i > 0) {
+            hipLaunchKernelGGL(pack_columns_kernel, dim3((kept + 255u) / 256u, b->vc.row_count), dim3(256), 0, b->stream, b->d_argb, b->vc.row_count,
+                               frame.width, col_begin, kept, bg_col, g_frame.d_packed[static_cast<size_t>(i)]);
+            AEHIP_FRAME_CHECK(hipGetLastError());
+        }
     }
 
-    // gather the peers' bands into device 0's frame.  Nothing here waits on the host: the RCCL
-    // receives are ordered on device 0's stream, and a device-to-device copy (bands that share
-    // device 0's GPU) ends in an event that device 0's stream waits on.
+    // Gather the peers' rows on device 0.  Nothing here waits on the host, and nothing waits for device
+    // 0's own render: the RCCL receives go to device 0's second stream and run beside that render (a
+    // device-to-device copy, for bands that share device 0's GPU, ends in an event); device 0's render
+    // stream waits for them only before it puts the frame together.
+    const uint32_t row_words = narrow ? kept : frame.width;
+    uint32_t *gathered = narrow ? g_frame.d_stack : b0->d_argb;
     if(n > 1 && distinct) {
         rccl_api &api = g_frame.rccl;
         AEHIP_FRAME_RCCL_CHECK(api, api.GroupStart());
         for(int i = 1; i < n; i++) {
             aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
-            const size_t count = static_cast<size_t>(frame.width) * b->vc.row_count;
+            const size_t count = static_cast<size_t>(row_words) * b->vc.row_count;
             AEHIP_FRAME_CHECK(hipSetDevice(b->device));
-            AEHIP_FRAME_RCCL_CHECK(api, api.Send(b->d_argb, count, ncclUint32, 0, g_frame.comms[static_cast<size_t>(i)], b->stream));
+            AEHIP_FRAME_RCCL_CHECK(api, api.Send(narrow ? g_frame.d_packed[static_cast<size_t>(i)] : b->d_argb, count, ncclUint32, 0,
+                                                 g_frame.comms[static_cast<size_t>(i)], b->stream));
             AEHIP_FRAME_CHECK(hipSetDevice(b0->device));
-            AEHIP_FRAME_RCCL_CHECK(api, api.Recv(b0->d_argb + static_cast<size_t>(frame.width) * offset[static_cast<size_t>(i)], count, ncclUint32, i,
-                                                 g_frame.comms[0], b0->stream));
+            AEHIP_FRAME_RCCL_CHECK(api, api.Recv(gathered + static_cast<size_t>(row_words) * offset[static_cast<size_t>(i)], count, ncclUint32, i,
+                                                 g_frame.comms[0], b0->copy_stream));
         }
         AEHIP_FRAME_RCCL_CHECK(api, api.GroupEnd());
+        AEHIP_FRAME_CHECK(hipSetDevice(b0->device));
+        AEHIP_FRAME_CHECK(hipEventRecord(g_frame.ev_received, b0->copy_stream));
+        AEHIP_FRAME_CHECK(hipStreamWaitEvent(b0->stream, g_frame.ev_received, 0));
     } else if(n > 1) {
         for(int i = 1; i < n; i++) {
             aehip_backend *b = g_frame.bands[static_cast<size_t>(i)];
-            const size_t bytes = static_cast<size_t>(frame.width) * b->vc.row_count * sizeof(uint32_t);
+            const size_t bytes = static_cast<size_t>(row_words) * b->vc.row_count * sizeof(uint32_t);
             AEHIP_FRAME_CHECK(hipSetDevice(b->device));
-            AEHIP_FRAME_CHECK(hipMemcpyPeerAsync(b0->d_argb + static_cast<size_t>(frame.width) * offset[static_cast<size_t>(i)], b0->device,
-                                                 b->d_argb, b->device, bytes, b->stream));
+            AEHIP_FRAME_CHECK(hipMemcpyPeerAsync(gathered + static_cast<size_t>(row_words) * offset[static_cast<size_t>(i)], b0->device,
+                                                 narrow ? g_frame.d_packed[static_cast<size_t>(i)] : b->d_argb, b->device, bytes, b->stream));
             AEHIP_FRAME_CHECK(hipEventRecord(b->ev_copy, b->stream));
             AEHIP_FRAME_CHECK(hipSetDevice(b0->device));
             AEHIP_FRAME_CHECK(hipStreamWaitEvent(b0->stream, b->ev_copy, 0));
         }
     }
 
-    // bands -> pinned staging
     AEHIP_FRAME_CHECK(hipSetDevice(b0->device));
-    AEHIP_FRAME_CHECK(hipMemcpyAsync(b0->h_staging, b0->d_argb, frame_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, b0->stream));
+    if(narrow) {
+        // device 0's own band joins the stack (its rows come first), then the frame's rows in image order
+        hipLaunchKernelGGL(pack_columns_kernel, dim3((kept + 255u) / 256u, b0->vc.row_count), dim3(256), 0, b0->stream, b0->d_argb, b0->vc.row_count,
+                           frame.width, col_begin, kept, bg_col, g_frame.d_stack);
+        const dim3 grid(((frame.width + 3u) / 4u + 255u) / 256u, frame.row_count);
+        if(frame.width % 4u == 0)
+            hipLaunchKernelGGL(expand_columns_kernel<true>, grid, dim3(256), 0, b0->stream, g_frame.d_stack, static_cast<unsigned long long>(frame.row_count),
+                               g_frame.d_row_source, frame.row_count, frame.width, col_begin, col_end, kept, g_frame.d_image);
+        else
+            hipLaunchKernelGGL(expand_columns_kernel<false>, grid, dim3(256), 0, b0->stream, g_frame.d_stack, static_cast<unsigned long long>(frame.row_count),
+                               g_frame.d_row_source, frame.row_count, frame.width, col_begin, col_end, kept, g_frame.d_image);
+        AEHIP_FRAME_CHECK(hipGetLastError());
+    }
+    // frame -> pinned staging
+    AEHIP_FRAME_CHECK(hipMemcpyAsync(b0->h_staging, narrow ? g_frame.d_image : b0->d_argb, frame_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, b0->stream));
     AEHIP_FRAME_CHECK(hipEventRecord(b0->ev_copy, b0->stream));
     AEHIP_FRAME_CHECK(hipStreamSynchronize(b0->stream));
 #undef AEHIP_FRAME_CHECK
 #undef AEHIP_FRAME_RCCL_CHECK
-    // pinned staging (band order) -> caller's buffer (image order), one copy per tile
-    for(int i = 0; i < n; i++) {
-        const uint32_t rows = band_rows[static_cast<size_t>(i)];
-        for(uint32_t j = 0; j < rows; j += T) {
-            const uint32_t tile = static_cast<uint32_t>(i) + (j / T) * static_cast<uint32_t>(n);
-            const uint32_t count = rows - j < T ? rows - j : T;
-            std::memcpy(framebuffer + static_cast<size_t>(frame.width) * tile * T,
-                        b0->h_staging + static_cast<size_t>(frame.width) * (offset[static_cast<size_t>(i)] + j),
-                        static_cast<size_t>(frame.width) * count * sizeof(uint32_t));
+    if(narrow) {
+        // the frame arrived in image order
+        std::memcpy(framebuffer, b0->h_staging, frame_pixels * sizeof(uint32_t));
+    } else {
+        // pinned staging (band order) -> caller's buffer (image order), one copy per tile
+        for(int i = 0; i < n; i++) {
+            const uint32_t rows = band_rows[static_cast<size_t>(i)];
+            for(uint32_t j = 0; j < rows; j += T) {
+                const uint32_t tile = static_cast<uint32_t>(i) + (j / T) * static_cast<uint32_t>(n);
+                const uint32_t count = rows - j < T ? rows - j : T;
+                std::memcpy(framebuffer + static_cast<size_t>(frame.width) * tile * T,
+                            b0->h_staging + static_cast<size_t>(frame.width) * (offset[static_cast<size_t>(i)] + j),
+                            static_cast<size_t>(frame.width) * count * sizeof(uint32_t));
+            }
         }
     }
 
@@ -3953,6 +4180,7 @@ extern "C" int aehip_trace_frame(int n_devices, const aehip_scene *scene, const 
             total.rays += st.rays;
             total.paths += st.paths;
             total.lane_slots += st.lane_slots;
+            total.samples_walked += st.samples_walked;
             total.vgprs = st.vgprs;
             total.lds_bytes = st.lds_bytes;
         }

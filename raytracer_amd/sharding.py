@@ -126,6 +126,7 @@ class BandGather:
         self._narrow = None             # set_columns(): per slot, the kept columns of the band behind a background pixel a row
         self._columns = None
         self._handle = None             # inside submit(): the communication stream's hipStream_t
+        self._prepacked = False         # inside submit(packed=True): the caller packed the kept columns already
         # on a GPU the library's kernels pack and expand (RAYTRACER_AMD_TORCH_COLUMNS=1: torch's gathers, for comparison)
         self._use_lib = self.on_gpu and os.environ.get("RAYTRACER_AMD_TORCH_COLUMNS") != "1"
         # per buffer: event after which the buffer may be rendered into again (an event is
@@ -162,15 +163,20 @@ class BandGather:
         quarter, switch it off).  Call between frames (nothing submitted and not finished)."""
         width = self.width
         col_begin, col_end = max(0, int(col_begin)), min(width, int(col_end))
-        if self._narrow is not None and self._columns == (col_begin, col_end):
+        kept = col_end - col_begin + 1
+        narrow = bool(self.collective and self._stacked and col_end > col_begin and kept * 4 <= width * 3
+                      and os.environ.get("RAYTRACER_AMD_WHOLE_ROWS") != "1")       # (1: whole rows on the wire, for comparison)
+        self._agree_on(col_begin, col_end, narrow)
+        if self._narrow is not None and narrow and self._columns == (col_begin, col_end):
             return True                 # as it is: the buffers and the element map stay
+        # The buffers of the previous columns may still be read by the communication or the reorder stream
+        # (a frame submitted and not finished): wait for both before they go back to the allocator.
+        if self._narrow is not None:
+            self.finish()
         self._narrow = None
         self._columns = (col_begin, col_end)
         device = self.locals[0].device
-        kept = col_end - col_begin + 1
-        if not self.collective or not self._stacked or col_end <= col_begin or kept * 4 > width * 3:
-            return False
-        if os.environ.get("RAYTRACER_AMD_WHOLE_ROWS") == "1":       # (whole rows on the wire, for comparison)
+        if not narrow:
             return False
         # a background pixel of each row: the first column if it is outside the kept ones, else the last
         bg = 0 if col_begin > 0 else width - 1
@@ -196,6 +202,21 @@ class BandGather:
             self._lib = raytracer_amd.load()
         return True
 
+    def _agree_on(self, col_begin: int, col_end: int, narrow: bool) -> None:
+        """Every rank must send the same shape: a rank with other columns, or one that kept whole rows, would
+        leave the gather waiting for bytes that never come.  One small all-reduce per call of set_columns
+        (between frames), min and max of the three numbers in one tensor."""
+        if not (dist.is_initialized() and self.world > 1):
+            return
+        mine = [col_begin, col_end, int(narrow)]
+        on = self.locals[0].device if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor(mine + [-v for v in mine], dtype=torch.int64, device=on)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        lo, hi = t[:3].tolist(), [-v for v in t[3:].tolist()]
+        if lo != hi:
+            raise RuntimeError(f"set_columns: ranks disagree on what they send (rank {self.rank}: columns {col_begin}..{col_end}, "
+                               f"narrow {narrow}; over ranks min {lo}, max {hi})")
+
     def _stream_handle(self) -> int:
         """hipStream_t of the stream the gather's own kernels go to: the communication stream inside submit(), else the current one."""
         return self._handle if self._handle is not None else torch.cuda.current_stream().cuda_stream
@@ -204,6 +225,8 @@ class BandGather:
         """The tensor this rank contributes for `slot`: the band, or its kept columns behind a background pixel a row."""
         if self._narrow is None:
             return self.locals[slot]
+        if self._prepacked:
+            return self._narrow[slot]
         if self._use_lib:
             c0, c1 = self._columns
             rc = self._lib.aehip_band_pack_columns(self.locals[slot].data_ptr(), self.max_rows, self.width, c0, c1, self._bg_col,
@@ -224,6 +247,7 @@ class BandGather:
 
     def gather(self) -> torch.Tensor | None:
         """Collects every rank's band from buffer 0; returns the assembled image on dst, None elsewhere."""
+        self._prepacked = False
         self._start(0, async_op=False)
         return self._assemble()
 
@@ -238,13 +262,29 @@ class BandGather:
             (stream if stream is not None else torch.cuda.current_stream()).wait_event(self._free[slot])
         return self.locals[slot]
 
-    def submit(self, frame: int, stream: "torch.cuda.Stream | None" = None) -> None:
+    def pack(self, slot: int, stream_handle: int) -> None:
+        """Packs buffer `slot`'s kept columns on the caller's stream (a hipStream_t), for callers that queue the
+        render and the pack together -- a HIP graph of the two, say -- and then submit(..., packed=True).
+        Nothing to do while whole rows are sent."""
+        if self._narrow is None:
+            return
+        if not self._use_lib:
+            raise RuntimeError("BandGather.pack needs the library's pack kernel (a GPU, RAYTRACER_AMD_TORCH_COLUMNS unset)")
+        c0, c1 = self._columns
+        rc = self._lib.aehip_band_pack_columns(self.locals[slot].data_ptr(), self.max_rows, self.width, c0, c1, self._bg_col,
+                                               self._narrow[slot].data_ptr(), stream_handle)
+        if rc != 0:
+            raise RuntimeError(f"aehip_band_pack_columns failed ({rc}): {self._lib.aehip_last_error().decode()}")
+
+    def submit(self, frame: int, stream: "torch.cuda.Stream | None" = None, packed: bool = False) -> None:
         """Starts the gather of the band rendered into begin(frame)'s buffer and returns at once.
         At most one gather is in flight: the previous frame's gather, which had that frame's
         successor render to hide behind, is completed (and its rows put in image order) first, so
         frames land in the destination image in order on any backend.
-        `stream`: the current stream (the one the band was rendered on), as for begin()."""
+        `stream`: the current stream (the one the band was rendered on), as for begin().
+        `packed`: the caller has packed the buffer's kept columns itself, behind the render (pack())."""
         slot = frame & 1
+        self._prepacked = packed and self._narrow is not None
         if self._stream_ordered:
             render_stream = stream if stream is not None else torch.cuda.current_stream()
             self._rendered[slot].record(render_stream)
@@ -311,8 +351,9 @@ class BandGather:
             return None
         if self._narrow is not None and self._use_lib:
             c0, c1 = self._columns
-            rc = self._lib.aehip_band_expand_columns(self._nrecvs[slot if len(self._nrecvs) > 1 else 0].data_ptr(), self._row_source.data_ptr(),
-                                                     self.height, self.width, c0, c1, self.image.data_ptr(), self._stream_handle())
+            rc = self._lib.aehip_band_expand_columns(self._nrecvs[slot if len(self._nrecvs) > 1 else 0].data_ptr(), self.world * self.max_rows,
+                                                     self._row_source.data_ptr(), self.height, self.width, c0, c1, self.image.data_ptr(),
+                                                     self._stream_handle())
             if rc != 0:
                 raise RuntimeError(f"aehip_band_expand_columns failed ({rc}): {self._lib.aehip_last_error().decode()}")
         elif self._narrow is not None:

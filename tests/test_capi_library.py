@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(raytracer_amd.AehipParams) == 48
     assert ctypes.sizeof(raytracer_amd.AehipScene) == 64
-    assert ctypes.sizeof(raytracer_amd.AehipStats) == 48
+    assert ctypes.sizeof(raytracer_amd.AehipStats) == 56
     assert raytracer_amd.SPHERE_DTYPE.itemsize == 48
 
 
@@ -131,21 +131,24 @@ def test_frame_band_arithmetic_equals_the_python_sharding(n, rows, tile):
 
 
 def test_committed_counters_were_measured_on_these_kernel_sources():
-    """bench.py prices its roofline figures from profiles/r02_counters.json and refuses a file
+    """bench.py prices its roofline figures from profiles/r03_counters.json and refuses a file
     collected on another version of the kernels: keep the committed file current (re-run
     tools/profile_bench.sh and tools/profile_scenes.sh on the GPU box after changing a kernel)."""
     import hashlib
     import json
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "profiles", "r02_counters.json")) as f:
+    with open(os.path.join(root, "profiles", "r03_counters.json")) as f:
         doc = json.load(f)
     h = hashlib.sha256()
     for rel in doc["kernel_sources"]:
         with open(os.path.join(root, rel), "rb") as f:
             h.update(f.read())
     assert doc["kernel_source_sha256"] == h.hexdigest()
-    for key in ("headline_fast", "headline_exact", "stress10k_1080p_4spp_d4_fast", "stress10k_1080p_4spp_d4_exact",
-                "stress10k_1080p_2spp_d1_fast", "divergence_1080p_16spp_d50_fast", "divergence_1080p_16spp_d50_exact"):
+    import bench
+
+    keys = ["headline_fast", "headline_exact", "headline_fast_walked", "headline_exact_walked"]
+    keys += [f"{name}_{mode}" for name in bench.CONFIG_CASES for mode in ("fast", "exact")]     # every workload bench.py prices
+    for key in keys:
         kernels = doc["workloads"][key]["kernels"]
         assert any("executed_fp32_flop_per_frame" in k for k in kernels.values()), key

@@ -314,14 +314,32 @@ def test_pixels_decided_by_bounds_equal_pixels_walked_sample_by_sample(view):
     if view != "default":
         kw["cam"] = cam
     w, h = 640, 360
-    argb, rgba, _ = render_device(w, h, **kw)
-    argb_all, rgba_all, _ = render_device(w, h, walk_all=True, **kw)
+    argb, rgba, st = render_device(w, h, **kw)
+    argb_all, rgba_all, st_all = render_device(w, h, walk_all=True, **kw)
     np.testing.assert_array_equal(rgba.view(np.uint32), rgba_all.view(np.uint32))
     np.testing.assert_array_equal(argb, argb_all)
-    _, fast, _ = render_device(w, h, fast=True, **kw)
-    _, fast_all, _ = render_device(w, h, fast=True, walk_all=True, **kw)
+    _, fast, st_fast = render_device(w, h, fast=True, **kw)
+    _, fast_all, st_fast_all = render_device(w, h, fast=True, walk_all=True, **kw)
     assert float(np.abs(fast - fast_all).max()) <= 2e-6
     assert float(np.abs(fast[..., :3] - rgba[..., :3]).max()) <= 1e-5
+    # aehip_stats.samples_walked: every sample with AEHIP_FLAG_WALK_ALL; else spp x the pixels that were not
+    # decided from bounds -- which include every pixel that holds anything but its row's background, and not
+    # many more (the silhouette's margin: a pixel or two around the sphere)
+    assert st_all.samples_walked == st_fast_all.samples_walked == st_all.paths == w * h * 70
+    for s_, img in ((st, rgba), (st_fast, fast)):
+        assert s_.samples_walked % 70 == 0 and s_.samples_walked <= s_.paths
+        walked = s_.samples_walked // 70
+        if view == "inside":
+            continue
+        shape_pixels = int((img[..., :3] != img[:, :1, :3]).any(axis=-1).sum())      # (column 0 is background in these views)
+        if view == "behind":
+            # nothing is seen.  The exact build walks what the line of sight passes through; the fast build only the
+            # ill-conditioned pixels along that disc's edge, whose sums in the reference's arithmetic differ from
+            # the product background x samples by rounding
+            assert float(np.abs(img[..., :3] - img[:, :1, :3]).max()) <= 1e-6
+            assert s_ is st or walked <= 6 * (w + h)
+        else:
+            assert shape_pixels <= walked <= shape_pixels + 6 * (w + h)
 
 
 @pytest.mark.parametrize("view,size,spp", [("default", (1920, 1080), 1024), ("off_axis_camera", (2560, 1440), 256),
@@ -714,6 +732,16 @@ def test_trace_frame_is_independent_of_the_number_of_bands(bands):
         np.testing.assert_array_equal(split, whole)
         assert st.paths == 130 * 75 * 3 and st.rays > st.paths
 
+    # The reference's scene through the camera pass, both builds, a width that is not a multiple of four
+    # among them: the library knows the columns that hold the sphere, so with several bands only those
+    # columns are gathered and device 0 rebuilds the rows (the same frame, bit for bit, as one band renders)
+    for fast in (False, True):
+        for w, h in ((640, 360), (402, 230)):
+            whole, _ = rt.render(w, h, spp=16, max_depth=8, seed=5, jitter=True, fast=fast)
+            split, st = rt.trace_frame(bands, w, h, spp=16, max_depth=8, seed=5, jitter=True, fast=fast)
+            np.testing.assert_array_equal(split, whole)
+            assert st.paths == w * h * 16 and 0 < st.samples_walked < st.paths
+
 
 def test_trace_frame_rejects_more_bands_than_rows():
     with pytest.raises(rt.HipRaytracerError):
@@ -908,6 +936,39 @@ def test_bands_of_the_full_size_scene_configurations_equal_the_oracle(case):
     got, st = rt.render(w, h, row_begin=row_begin, row_count=row_count, count_rays=True, **kw)
     np.testing.assert_array_equal(got, want)
     assert st.rays == rays
+
+
+@pytest.mark.parametrize("case", ["stress10k_4k_4spp_d4", "stress10k_4k_2spp_d1", "divergence_4k_16spp_d50", "config2_1080p_64spp_d8"])
+def test_bands_of_the_benchmarks_other_configurations_at_the_size_the_metric_names(case):
+    """bench.py's own requests for the 10,000-sphere scene and the depth-50 scene at 3840x2160 (and the
+    default scene at 1920x1080 with 64 samples): bands of those frames, exact build, are the CPU oracle's
+    bands bit for bit with the oracle's ray count; the fast build renders the same paths up to rare
+    branch flips."""
+    import bench
+
+    w, h, spp, depth, seed, scene = bench.CONFIG_CASES[case]
+    sph = {"default": None, "stress10k": scenes.stress_scene(10000, 42), "divergence": scenes.divergence_scene(300, 7)}[scene]
+    kw = dict(spp=spp, max_depth=depth, seed=seed, jitter=True, spheres=sph)
+    bands = [(0, 4), (h // 2 - 4, 4)] if scene != "default" else [(0, 8), (300, 8), (536, 8)]
+    for row_begin, row_count in bands:
+        want, _, rays, _ = oracle.trace_paths(w, h, row_begin=row_begin, row_count=row_count, threads=16, **kw)
+        got, st = rt.render(w, h, row_begin=row_begin, row_count=row_count, count_rays=True, **kw)
+        np.testing.assert_array_equal(got, want)
+        assert st.rays == rays
+        fast, _ = rt.render(w, h, row_begin=row_begin, row_count=row_count, fast=True, **kw)
+        diff = np.abs(channels(fast) - channels(want)).max(axis=-1)
+        if scene == "default":
+            assert diff.max() <= 4 and np.count_nonzero(diff > 1) <= 1e-4 * w * row_count
+        elif depth == 1:
+            # one segment a path: the same hits but for rays within rounding of a silhouette
+            assert np.count_nonzero(diff > 1) <= 2e-3 * w * row_count, (case, row_begin, int(np.count_nonzero(diff > 1)))
+        else:
+            # Bounced paths: a scattered direction that differs in its last bits meets other spheres a few bounces
+            # on, so single pixels differ (measured: 13 % of the pixels of a 4-sample band by more than two code
+            # values) while the band's mean colour, an average over the same distribution of paths, does not
+            assert np.count_nonzero(diff > 2) <= 0.25 * w * row_count, (case, row_begin, int(np.count_nonzero(diff > 2)))
+            mean_shift = np.abs(channels(fast).reshape(-1, 3).mean(axis=0) - channels(want).reshape(-1, 3).mean(axis=0))
+            assert float(mean_shift.max()) <= 1.0, (case, row_begin, mean_shift)
 
 
 @pytest.mark.parametrize("fast", [True, False], ids=["fast", "exact"])

@@ -71,11 +71,14 @@ def test_frames_arrive_whole_and_in_order_with_frames_on_alternating_streams(sin
     assert bool((image == frames).all())
 
 
-@pytest.mark.parametrize("untimed,columns", [(False, False), (True, False), (True, True)])
-def test_rendered_frames_through_the_two_stream_pipeline_equal_the_single_launch(single_rank_rccl, untimed, columns):
+@pytest.mark.parametrize("untimed,columns,graphed", [(False, False, False), (True, False, False), (True, True, False), (True, True, True),
+                                                     (True, False, True)])
+def test_rendered_frames_through_the_two_stream_pipeline_equal_the_single_launch(single_rank_rccl, untimed, columns, graphed):
     """untimed: the benchmark's form of the loop -- the library records no timing events
     (AEHIP_FLAG_NO_TIMING) and begin() / submit() are handed the stream instead of looking it up.
-    columns: only the columns the library reports as more than background are gathered."""
+    columns: only the columns the library reports as more than background are gathered.
+    graphed: a frame's render (through the entry point that allocates nothing) and the pack of its kept columns
+    are captured once per band buffer into a HIP graph and replayed; the collective stays outside the graph."""
     import torch
 
     device = torch.device("cuda", 0)
@@ -89,13 +92,27 @@ def test_rendered_frames_through_the_two_stream_pipeline_equal_the_single_launch
         assert 0 < c0 < c1 < width and (c1 - c0) < width * 0.6
         assert g.set_columns(c0, c1)
     streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+    graphs = []
+    if graphed:
+        for slot in range(2):
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=streams[slot], capture_error_mode="thread_local"):
+                back.trace_device_static(g.locals[slot].data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+                g.pack(slot, torch.cuda.current_stream().cuda_stream)
+            graphs.append(graph)
     for i in range(7):
         side = streams[i & 1]
         torch.cuda.set_stream(side)
         band = g.begin(i, side if untimed else None)
-        back.trace_device(band.data_ptr(), None, side.cuda_stream)
-        g.submit(i, side if untimed else None)
+        if graphed:
+            band.fill_(0)           # (whatever the buffer held: the replay must render the frame anew)
+            graphs[i & 1].replay()
+        else:
+            back.trace_device(band.data_ptr(), None, side.cuda_stream)
+        g.submit(i, side if untimed else None, packed=graphed)
     image = g.finish()
+    del graphs
     torch.cuda.synchronize()
     st = back.stats()
     assert (st.kernel_ms == 0.0) if untimed else (st.kernel_ms > 0.0)
@@ -184,10 +201,22 @@ def test_pack_and_expand_kernels_against_their_definition(shape):
     assert torch.equal(packed, want)
     order = torch.randperm(rows, generator=gen).cuda()
     image = torch.zeros((rows, width), dtype=torch.int32, device="cuda")
-    assert lib.aehip_band_expand_columns(packed.data_ptr(), order.data_ptr(), rows, width, c0, c1, image.data_ptr(), stream) == 0
+    assert lib.aehip_band_expand_columns(packed.data_ptr(), rows, order.data_ptr(), rows, width, c0, c1, image.data_ptr(), stream) == 0
     torch.cuda.synchronize()
     rebuilt = band[order][:, bg:bg + 1].expand(rows, width).clone()
     rebuilt[:, c0:c1] = band[order][:, c0:c1]
     assert torch.equal(image, rebuilt)
     assert lib.aehip_band_pack_columns(band.data_ptr(), rows, width, c1, c0, bg, packed.data_ptr(), stream) == -2
-    assert lib.aehip_band_expand_columns(None, order.data_ptr(), rows, width, c0, c1, image.data_ptr(), stream) == -2
+    assert lib.aehip_band_expand_columns(None, rows, order.data_ptr(), rows, width, c0, c1, image.data_ptr(), stream) == -2
+    # a background column among the kept ones would send a pixel of the shape as the row's background
+    assert lib.aehip_band_pack_columns(band.data_ptr(), rows, width, c0, c1, c0, packed.data_ptr(), stream) == -2
+    assert b"inside the kept columns" in lib.aehip_last_error()
+    # row indices outside the packed rows are never read through: those image rows keep what they held
+    wild = order.clone()
+    wild[0], wild[rows - 1] = -1, rows + 5
+    image.fill_(-7)
+    assert lib.aehip_band_expand_columns(packed.data_ptr(), rows, wild.data_ptr(), rows, width, c0, c1, image.data_ptr(), stream) == 0
+    torch.cuda.synchronize()
+    assert bool((image[0] == -7).all()) and bool((image[rows - 1] == -7).all())
+    assert torch.equal(image[1:rows - 1], rebuilt[1:rows - 1])
+    assert lib.aehip_band_expand_columns(packed.data_ptr(), 0, order.data_ptr(), rows, width, c0, c1, image.data_ptr(), stream) == -2

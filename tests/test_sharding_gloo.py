@@ -194,3 +194,29 @@ def test_gather_of_kept_columns_rebuilds_the_image(tmp_path, world, size, overla
     out = str(tmp_path / "image.npy")
     mp.spawn(_worker_columns, args=(world, free_port(), width, height, out, overlapped, synthetic), nprocs=world, join=True)
     assert np.array_equal(np.load(out), np.load(out + ".want.npy"))
+
+
+def _worker_disagreeing(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = BandGather(128, 72, torch.device("cpu"))
+        try:
+            g.set_columns(32 + 16 * rank, 96)           # every rank with a first column of its own
+            outcome = "accepted"
+        except RuntimeError as exc:
+            outcome = str(exc)
+        with open(f"{out_path}.{rank}", "w") as f:
+            f.write(outcome)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_that_disagree_on_the_columns_are_told_so_instead_of_waiting_in_the_gather(tmp_path):
+    """A rank that packed other columns than its peers would send another number of bytes than the destination
+    expects, and the gather would never complete: set_columns compares the columns over the ranks first."""
+    out = str(tmp_path / "outcome")
+    mp.spawn(_worker_disagreeing, args=(2, free_port(), out), nprocs=2, join=True)
+    for rank in range(2):
+        text = open(f"{out}.{rank}").read()
+        assert "ranks disagree" in text and f"rank {rank}" in text

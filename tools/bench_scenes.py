@@ -14,6 +14,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (bench.py's CONFIG_CASES: BASELINE's other configurations at the sizes it names)
 import raytracer_amd as rt  # noqa: E402
 from raytracer_amd import scenes  # noqa: E402
 
@@ -32,6 +33,11 @@ CASES = {
     "divergence600_1080p_8spp_d50": (1920, 1080, 8, 50, lambda: scenes.divergence_scene(600, 7)),
     "divergence1200_1080p_4spp_d50": (1920, 1080, 4, 50, lambda: scenes.divergence_scene(1200, 7)),
 }
+SEEDS = {}
+_SCENES = {"default": scenes.default_scene, "stress10k": lambda: scenes.stress_scene(10000, 42), "divergence": lambda: scenes.divergence_scene(300, 7)}
+for _name, (_w, _h, _spp, _depth, _seed, _scene) in bench.CONFIG_CASES.items():     # the cases bench.py times, same requests
+    CASES[_name] = (_w, _h, _spp, _depth, _SCENES[_scene])
+    SEEDS[_name] = _seed
 
 
 def main():
@@ -50,7 +56,7 @@ def main():
         back = rt.HipRaytracer(None)
         flags = rt.FLAG_JITTER | rt.FLAG_COUNT_RAYS | (rt.FLAG_FAST if args.mode == "fast" else 0) \
             | (rt.FLAG_NO_REGEN if args.no_regen else 0)
-        assert back.setup(w, h, spp=spp, max_depth=depth, seed=1, flags=flags, pass_=rt.PASS_PATH, spheres=sph, list_source=args.list), back.last_error()
+        assert back.setup(w, h, spp=spp, max_depth=depth, seed=SEEDS.get(name, 1), flags=flags, pass_=rt.PASS_PATH, spheres=sph, list_source=args.list), back.last_error()
         argb = torch.zeros((h, w), dtype=torch.int32, device="cuda")
         best = None
         for _ in range(args.reps):

@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """Folds the rocprofv3 --pmc outputs of tools/profile_bench.sh / tools/profile_scenes.sh into
-profiles/r02_counters.json, the file bench.py prices its roofline figures from.
+profiles/r03_counters.json, the file bench.py prices its roofline figures from.
 
-    python tools/collect_counters.py <workload key> <frames> <profile dir> [<profile dir> ...]
+    python tools/collect_counters.py <workload key> <frames | auto> <profile dir> [<profile dir> ...]
+
+<frames>: frames rendered in each profiled run; "auto" = the number of dispatches of the kernel with the
+largest total duration (bench.py's headline frames are one dispatch of the camera kernel each, however
+many frames its time-based warm-up renders).
 
 <profile dir> holds pmc_*/pmc_results.db (rocpd sqlite).  For every renderer kernel the file keeps
 the per-FRAME totals of each counter (sum over the run's dispatches / frames rendered in it), the
@@ -25,10 +29,10 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "profiles", "r02_counters.json")
+OUT = os.path.join(ROOT, "profiles", "r03_counters.json")
 KERNEL_SOURCES = ["raytracer_amd/csrc/hip_raytracer_kernels.hip", "raytracer_amd/csrc/rt_exact_math.h"]
 KERNELS = ["camera_hybrid_kernel", "camera_kernel", "primary_kernel", "path_stream_first_hits_kernel", "path_stream_kernel",
-           "first_hit_kernel", "path_kernel", "resolve_block_kernel", "ring_pixels_kernel"]
+           "first_hit_kernel", "path_kernel", "resolve_block_kernel", "ring_pixels_kernel", "walked_pixels_kernel"]
 
 
 def kernel_source_sha256():
@@ -47,7 +51,7 @@ def short_name(full):
 
 
 def main():
-    key, frames = sys.argv[1], int(sys.argv[2])
+    key, frames_arg = sys.argv[1], sys.argv[2]
     kernels = {}
     for d in sys.argv[3:]:
         for sub in sorted(os.listdir(d)):
@@ -58,6 +62,14 @@ def main():
             rows = con.execute("select kernel_name, counter_name, sum(value), count(*), avg(duration) from counters_collection "
                                "group by kernel_name, counter_name").fetchall()
             con.close()
+            if frames_arg == "auto":
+                # this pass's frames: dispatches of the renderer kernel that took the most time in it
+                busiest = max((r for r in rows if short_name(r[0]) is not None), key=lambda r: r[3] * r[4], default=None)
+                if busiest is None:
+                    continue
+                frames = busiest[3]
+            else:
+                frames = int(frames_arg)
             for full, counter, total, n, dur in rows:
                 name = short_name(full)
                 if name is None:
@@ -86,7 +98,7 @@ def main():
     doc["kernel_sources"] = KERNEL_SOURCES
     doc["note"] = ("per-frame totals of rocprofv3 --pmc counters (SQ counters are summed over the chip); collected by "
                    "tools/profile_bench.sh and tools/profile_scenes.sh, folded by tools/collect_counters.py")
-    doc["workloads"][key] = {"frames_in_run": frames, "kernels": kernels}
+    doc["workloads"][key] = {"frames_in_run": frames_arg if frames_arg == "auto" else int(frames_arg), "kernels": kernels}
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     with open(OUT, "w") as f:
         json.dump(doc, f, indent=1, sort_keys=True)

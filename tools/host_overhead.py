@@ -16,6 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--timed", action="store_true", help="the loop as it was before: library timing events, streams looked up")
+    ap.add_argument("--graph", action="store_true", help="bench.py's default: a frame's render and pack replayed from a HIP graph")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -42,14 +43,30 @@ def main():
     sides = [side, torch.cuda.Stream(device=device)]
     handles = [s.cuda_stream for s in sides]
 
+    graphs = None
+    if a.graph:
+        assert not a.timed, "--graph needs the untimed request (AEHIP_FLAG_NO_TIMING)"
+        back.trace_device_static(g.locals[0].data_ptr(), None, handles[0])
+        graphs = []
+        for slot in range(2):
+            gr = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(gr, stream=sides[slot], capture_error_mode="thread_local"):
+                back.trace_device_static(g.locals[slot].data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+                g.pack(slot, torch.cuda.current_stream().cuda_stream)
+            graphs.append(gr)
+
     def loop(n):
         # bench.py's timed loop for several ranks: frames on two streams in turn, gather submitted behind each
         for i in range(n):
             side = sides[i & 1]
             torch.cuda.set_stream(side)
             band = g.begin(i, None if a.timed else side)
-            back.trace_device(band.data_ptr(), None, handles[i & 1])
-            g.submit(i, None if a.timed else side)
+            if graphs is not None:
+                graphs[i & 1].replay()
+            else:
+                back.trace_device(band.data_ptr(), None, handles[i & 1])
+            g.submit(i, None if a.timed else side, packed=graphs is not None)
         torch.cuda.set_stream(sides[0])
         g.finish()
 
