@@ -51,7 +51,9 @@ in the line names the columns and the bytes a peer sends a frame).  --graph: a r
 allocation-free entry point, then the pack of its kept columns) is captured once into a HIP graph and
 replayed per frame, the collective staying outside the graph (on this runtime a replay costs the host
 0.073 ms a frame against 0.055 ms for the plain launches, tools/host_overhead.py, so plain launches are the default).
-BENCH_FORCE_COLLECTIVE=1 runs the multi-rank loop with a one-rank RCCL group on a one-GPU box.
+Rehearsals on a one-GPU box: BENCH_FORCE_COLLECTIVE=1 runs the multi-rank loop with a one-rank RCCL group;
+BENCH_SHARE_GPUS=1 under torch.distributed.run lets several ranks share the GPU, with gloo in RCCL's place (the same
+control flow: every rank must make the same collective calls in the same order).
 """
 import argparse
 import json
@@ -278,7 +280,13 @@ def main():
         sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    dev_index = local_rank
+    # one rank per GPU.  BENCH_SHARE_GPUS=1 (a rehearsal of the multi-rank control flow on a box with fewer GPUs than
+    # ranks): ranks share devices, and the bands are gathered as host tensors over gloo (every frame copied to the
+    # host first), since RCCL needs a GPU of its own for every rank.  (gloo's gather of DEVICE tensors between
+    # processes that share a GPU completes in most runs and, in some, never returns from wait() on any rank --
+    # tools/share_gpu_rehearsal.py -- so the rehearsal keeps it out of its way.)
+    share = os.environ.get("BENCH_SHARE_GPUS") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     # BENCH_FORCE_COLLECTIVE=1: the multi-rank code path (process group, two render streams,
@@ -289,7 +297,10 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29541")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     # everything runs on side streams: the library treats the null stream as "use your own and
     # wait", and launches are to queue back to back without the host in between.  With several
@@ -301,7 +312,10 @@ def main():
     torch.cuda.set_stream(sides[0])
     stream = sides[0].cuda_stream
     handles = [s.cuda_stream for s in sides]
-    gather = BandGather(WIDTH, HEIGHT, device, always_collective=grouped)
+    gather = BandGather(WIDTH, HEIGHT, torch.device("cpu") if share else device, always_collective=grouped)
+    collective_device = torch.device("cpu") if share else device       # where the loop's own small all-reduces live
+    host_frames = share             # the rehearsal: render into a device buffer, hand the band over as a host tensor
+    device_bands = [torch.zeros((gather.max_rows, WIDTH), dtype=torch.int32, device=device) for _ in range(2)] if host_frames else None
 
     verified = {}
     kept_columns = {}
@@ -328,9 +342,9 @@ def main():
         # (capture mode "thread_local": the process group's watchdog thread may touch the runtime meanwhile)
         graphs = None
         # (one plain launch first: the library reads the kernel's resource figures outside capture only)
-        back.trace_device_static(gather.locals[0].data_ptr(), None, stream)
+        back.trace_device_static((device_bands[0] if host_frames else gather.locals[0]).data_ptr(), None, stream)
         torch.cuda.synchronize()
-        if args.graph:
+        if args.graph and not host_frames:
             graphs = []
             for slot in range(2 if grouped else 1):
                 side = sides[slot % len(sides)]
@@ -348,14 +362,17 @@ def main():
             side = sides[i % len(sides)]
             torch.cuda.set_stream(side)
             band = gather.begin(i, side)
+            target = device_bands[i & 1] if host_frames else band
             if first is not None:
                 first.record()
             if graphs is not None:
                 graphs[i % len(graphs)].replay()
             else:
-                back.trace_device(band.data_ptr(), None, handles[i % len(sides)])
+                back.trace_device(target.data_ptr(), None, handles[i % len(sides)])
             if last is not None:
                 last.record()
+            if host_frames:
+                band.copy_(target)          # (waits for the render)
             gather.submit(i, side, packed=graphs is not None and grouped)
 
         def drain():
@@ -363,14 +380,21 @@ def main():
             gather.finish()
             torch.cuda.synchronize()
 
-        # settled clocks: frames for a fixed time, then the counted warm-up
+        # settled clocks: frames for a fixed time, then the counted warm-up.  Every frame is a collective, so the
+        # ranks must render the same number of them: they go round after round until no rank's clock says "more"
         t_pre = time.perf_counter()
         n_pre = 0
-        while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+        more = args.prewarm_ms > 0.0
+        while more:
             for _ in range(16):         # (an even number of frames a round: frame numbering starts on buffer 0 again)
                 frame(n_pre)
                 n_pre += 1
             torch.cuda.synchronize()
+            more = (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms
+            if grouped:
+                flag = torch.tensor([1 if more else 0], dtype=torch.int32, device=collective_device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                more = bool(flag.item())
         drain()
         prewarm_ms = (time.perf_counter() - t_pre) * 1e3
         for i in range(warmup + (warmup & 1)):
@@ -399,7 +423,7 @@ def main():
         else:
             kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
         mine = kernel_ms
-        t = torch.tensor([elapsed, kernel_ms * 1e-3], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, kernel_ms * 1e-3], dtype=torch.float64, device=collective_device)
         if grouped:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         st = back.stats()
@@ -421,11 +445,12 @@ def main():
             whole.trace_device(ref.data_ptr(), None, stream)
             torch.cuda.synchronize()
             whole.close()
-            verified[name] = same = bool(torch.equal(ref, gather.image))
+            got = gather.image.to(device)
+            verified[name] = same = bool(torch.equal(ref, got))
             if not same:
-                ne = ref != gather.image
+                ne = ref != got
                 idx = ne.nonzero()[:6].tolist()
-                print("MISMATCH", mode, int(ne.sum()), idx, [(hex(ref[y, x].item() & 0xffffffff), hex(gather.image[y, x].item() & 0xffffffff)) for y, x in idx], file=sys.stderr, flush=True)
+                print("MISMATCH", mode, int(ne.sum()), idx, [(hex(ref[y, x].item() & 0xffffffff), hex(got[y, x].item() & 0xffffffff)) for y, x in idx], file=sys.stderr, flush=True)
         walked = sum(r["samples_walked"] for r in per_rank) if per_rank else int(st.samples_walked)
         return {"elapsed_s": float(t[0]), "kernel_s": float(t[1]), "stats": st, "steps": steps, "prewarm_ms": prewarm_ms,
                 "samples_walked": walked, "per_rank": per_rank}
@@ -533,10 +558,10 @@ def main():
                           "bytes_per_peer_per_frame": {k: gather.max_rows * 4 * ((v[1] - v[0] + 1) if v else WIDTH) for k, v in kept_columns.items()}}
         if head["per_rank"]:
             ranks = head["per_rank"]
-            line["rccl"] = {"rccl_ranks": len(ranks), "distinct_devices": len({r["uuid"] for r in ranks}),
+            line["rccl"] = {"rccl_ranks": len(ranks), "backend": dist.get_backend(), "distinct_devices": len({r["uuid"] for r in ranks}),
                             "kernel_ms_min": min(r["kernel_ms"] for r in ranks), "kernel_ms_max": max(r["kernel_ms"] for r in ranks),
                             "ranks": ranks}
-            summary["rccl"] = {"rccl_ranks": len(ranks), "distinct_devices": len({r["uuid"] for r in ranks}),
+            summary["rccl"] = {"rccl_ranks": len(ranks), "backend": dist.get_backend(), "distinct_devices": len({r["uuid"] for r in ranks}),
                                "kernel_ms_min": sig(min(r["kernel_ms"] for r in ranks)), "kernel_ms_max": sig(max(r["kernel_ms"] for r in ranks))}
         if world == 1 and not args.no_aux:
             line["aux"] = aux_measurements(rt, torch, stream, counters, args.prewarm_ms)

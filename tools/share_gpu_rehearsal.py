@@ -4,6 +4,13 @@ device tensors between processes, for boxes with fewer GPUs than ranks (RCCL nee
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29577 \
         tools/share_gpu_rehearsal.py [--frames 4] [--whole-rows] [--overlapped]
 
+What it has shown on this image (ROCm 7.2, torch 2.10): both forms complete and verify in most runs (two ranks, 4 frames,
+narrow buffers, blocking and overlapped), while the same overlapped exchange inside a longer loop (bench.py with two
+ranks, a few dozen frames) ended with every rank inside Work.wait() of the same frame's gather and no rank ahead or
+behind -- the ranks agreed on shapes and call counts (BandGather.set_columns checks the former), so the stall is inside
+gloo's staging of device tensors, not in what the ranks asked for.  bench.py's shared-GPU rehearsal therefore hands
+gloo host tensors; RCCL, the product path, has its own stream-ordered form of the gather.
+
 Every rank prints what it is about to contribute (shape of the packed band, the receive buffers' shapes on the
 destination, whether the narrow form is on) before each collective, dumps its stacks and exits if a call has not
 returned after --watchdog seconds, and rank 0 checks the gathered frame against the frame it renders alone.

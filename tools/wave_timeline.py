@@ -19,7 +19,7 @@ import raytracer_amd as rt
 lib = rt.load()
 if not hasattr(lib, "aehip_wave_timeline"):
     sys.exit("this library has no timeline: build it with `make timeline` and point RAYTRACER_AMD_LIB at it")
-W, H = 3840, 2160
+W, H = (int(v) for v in os.environ.get("TIMELINE_SIZE", "3840x2160").split("x"))      # TIMELINE_SIZE=1920x1080: another frame size
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 back = rt.HipRaytracer(None)
 band = {}
@@ -29,7 +29,7 @@ if len(sys.argv) > 4:
 assert back.setup(W, H, spp, 8, 1, rt.FLAG_JITTER | rt.FLAG_FAST, rt.PASS_PATH, spheres=None, **band), back.last_error()
 argb = torch.zeros((H, W), dtype=torch.int32, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
-for _ in range(4):
+for _ in range(int(os.environ.get("TIMELINE_LAUNCHES", "4"))):         # (the last launch's stamps are read; more launches, warmer clocks)
     back.trace_device(argb.data_ptr(), None, stream)
 torch.cuda.synchronize()
 cap = 1 << 18
