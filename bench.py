@@ -664,6 +664,24 @@ def aux_measurements(rt, torch, stream, counters, prewarm_ms):
                 continue
             img = torch.zeros((h, w), dtype=torch.int32, device="cuda")
             ms, s = settled_launches(back, img, torch, stream, prewarm_ms, launches=3 if regen else 2)
+            if ms < 1.0:
+                # A launch of tens of microseconds: the library's pair of timing events adds several microseconds of its
+                # own (the profiler's trace of the 1920x1080 64-sample frame says 24-26 us where the pair says 33).  Such
+                # frames are queued back to back without library events (AEHIP_FLAG_NO_TIMING) between ONE pair of
+                # events and the span is divided: a frame's time as a caller that queues frames sees it.
+                quick = rt.HipRaytracer(None)
+                if quick.setup(w, h, spp=spp, max_depth=depth, seed=seed, flags=flags | rt.FLAG_NO_TIMING, pass_=rt.PASS_PATH, spheres=sph):
+                    batch = 200
+                    for _ in range(50):
+                        quick.trace_device(img.data_ptr(), None, stream)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(batch):
+                        quick.trace_device(img.data_ptr(), None, stream)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1) / batch
+                quick.close()
             n_spheres = 1 if sph is None else len(sph)
             entry = {"kernel_ms": ms, "mpaths_per_s": s.paths / ms / 1e3, "rays_per_s": s.rays / (ms * 1e-3),
                      "rays_per_path": s.rays / s.paths, "lane_utilisation": s.rays / s.lane_slots if s.lane_slots else None,

@@ -175,8 +175,9 @@ int aehip_backend_trace_device(aehip_backend *backend, uint32_t *argb_dev, float
  * the process ends.  A band whose strips do not fit the array at once is rendered in several
  * passes over it; AEHIP_E_TOO_LARGE beyond 4096 passes (about 5.5 million 16x4-pixel strips at
  * 64 or more samples per pixel).  The array keeps the last call's contents (the call clears
- * what must start at zero); every call on a GPU shares that GPU's array, so calls that overlap
- * on one GPU race -- issue them on one stream, or wait for one before starting the next.
+ * what must start at zero); every call on a GPU shares that GPU's array.  Outside stream capture the
+ * library orders the calls that use it after one another (an event per GPU, whichever backends and
+ * streams the calls come from), so they do not race; they do not run side by side either.
  * Passes that use no scratch (the reference's pass, the camera pass, the per-lane path pass
  * without AEHIP_FLAG_COUNT_RAYS) run exactly as through aehip_backend_trace_device.
  * Under stream capture (hip_stream is capturing into a HIP graph): the request must carry

@@ -90,3 +90,43 @@ def test_static_scratch_entry_point_rejects_a_band_beyond_its_limit():
             back.trace_device_static(argb.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
     finally:
         back.close()
+
+
+def test_two_backends_on_two_streams_take_turns_on_the_gpus_scratch_array():
+    """The fixed array is one per GPU, whichever backend calls.  Two backends whose static calls go to two streams,
+    queued in alternation without waiting in between, must each get its own allocating call's image and ray count:
+    the library orders scratch users on a GPU after one another (an event per GPU), and a backend reads its ray
+    counters back before another backend's next launch can clear them (stats() waits for the GPU first)."""
+    import torch
+
+    sph = scenes.divergence_scene()
+    flags = rt.FLAG_JITTER | rt.FLAG_COUNT_RAYS
+    requests = [(320, 180, 6, 12, 21), (200, 120, 5, 20, 7)]
+    backs, wants = [], []
+    try:
+        for (w, h, spp, depth, seed) in requests:
+            back = rt.HipRaytracer(None)
+            assert back.setup(w, h, spp, depth, seed, flags, rt.PASS_PATH, spheres=sph), back.last_error()
+            ref = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+            back.trace_device(ref.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            backs.append(back)
+            wants.append((ref, back.stats().rays))
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = [torch.zeros_like(ref) for ref, _ in wants]
+        torch.cuda.synchronize()
+        for round_ in range(3):
+            for k in (0, 1):
+                outs[k].fill_(0x55)
+                streams[k].wait_stream(torch.cuda.current_stream())
+                backs[k].trace_device_static(outs[k].data_ptr(), None, streams[k].cuda_stream)
+            for k in (1, 0):
+                streams[k].synchronize()
+                assert torch.equal(outs[k], wants[k][0]), (round_, k)
+        # ray counts: the array's counters belong to whoever launched last, so they are read per backend, launch by launch
+        for k in (0, 1):
+            backs[k].trace_device_static(outs[k].data_ptr(), None, streams[k].cuda_stream)
+            assert backs[k].stats().rays == wants[k][1]
+    finally:
+        for back in backs:
+            back.close()
