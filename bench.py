@@ -37,7 +37,7 @@ The line also carries
                 timed on this host's cores on a bounded sample of the same frame, plus the real
                 reference binary's 1-sample figure where oracle/_ref was shipped,
   aux           (N=1, unless --no-aux) the reference-pinned primary pass at 4K against HBM store
-                bandwidth, the host-buffer call's wall time, and BASELINE's other configurations at the
+                bandwidth, the host-buffer call's wall time, and the benchmark's other configurations at the
                 sizes it names: 1920x1080 / 64 spp / depth 8 on the default scene, the 10,000-sphere
                 brute-force scene and the depth-50 mixed-material scene at 3840x2160, each against the FP32
                 vector peak from counters of the same launches (mean of settled launches, not best-of),
@@ -81,7 +81,7 @@ COUNTERS_FILE = os.path.join(ROOT, "profiles", "r03_counters.json")
 KERNEL_SOURCES = ["raytracer_amd/csrc/hip_raytracer_kernels.hip", "raytracer_amd/csrc/rt_exact_math.h"]
 SETUP_KERNELS = ("ring_pixels_kernel", "walked_pixels_kernel", "row_miss_sums_kernel")
 
-# BASELINE's other configurations at the sizes it names, shared with tools/bench_scenes.py (the counters'
+# the benchmark's other configurations at the sizes it names, shared with tools/bench_scenes.py (the counters'
 # workload keys are "<name>_<mode>"): name -> (width, height, spp, depth, seed, scene)
 CONFIG_CASES = {
     "config2_1080p_64spp_d8": (1920, 1080, 64, 8, 1, "default"),
@@ -647,7 +647,7 @@ def aux_measurements(rt, torch, stream, counters, prewarm_ms):
             "ms_per_call": wall, "mpaths_per_s": WIDTH * HEIGHT * 1024 / wall / 1e3, "kernel_ms": st.kernel_ms,
             "copy_tail_ms": st.copy_ms, "note": "aehip_backend_trace: wall time seen by the caller, frame delivered in host memory",
         }
-    # BASELINE's other configurations at the sizes it names.  The brute-force list: every ray tests every sphere,
+    # the benchmark's other configurations at the sizes it names.  The brute-force list: every ray tests every sphere,
     # 18 flop per test as the reference writes it (depth 1: camera rays only, the table of per-sphere camera
     # constants, 4 operations a test; depth 4: the streamed pass, rays from anywhere, 10 operations a test).
     # The divergence scene: lane utilisation of the bounce loop with and without path regeneration.

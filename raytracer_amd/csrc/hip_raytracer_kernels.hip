@@ -1633,16 +1633,16 @@ __global__ __launch_bounds__(256) void ring_pixels_kernel(view_consts vc, camera
 // Pixels of the band that the single-sphere camera pass walks through a sample loop: all but those
 // camera_body culls from the same classification (every sample misses; fast build: also a sphere
 // that only the far side of the camera faces).  Listed pixels are walked, in the reference's
-// arithmetic.  One atomic a wave.
+// arithmetic.
 __global__ __launch_bounds__(256) void walked_pixels_kernel(view_consts vc, camera_consts cc, uint32_t fast, uint32_t *__restrict__ count) {
     // a few hundred workgroups stride over the band: atomics on one word go through one at a time, so one a workgroup
     __shared__ uint32_t s_count;
     if(threadIdx.x == 0u) s_count = 0u;
     __syncthreads();
-    const uint32_t pixels = vc.width * vc.row_count;
+    const unsigned long long pixels = static_cast<unsigned long long>(vc.width) * vc.row_count;
     uint32_t mine = 0;
-    for(uint32_t gid = blockIdx.x * 256u + threadIdx.x; gid < pixels; gid += gridDim.x * 256u) {
-        const uint32_t row = gid / vc.width, x = gid - row * vc.width;
+    for(unsigned long long gid = blockIdx.x * 256u + threadIdx.x; gid < pixels; gid += gridDim.x * 256u) {
+        const uint32_t row = static_cast<uint32_t>(gid / vc.width), x = static_cast<uint32_t>(gid - static_cast<unsigned long long>(row) * vc.width);
         const pixel_class pc = classify_pixel(vc, cc, x, image_row(vc, row));
         bool culled = !pc.may_hit;
         if(fast != 0u && cc.near_root_only != 0u && pc.may_hit && pc.well_conditioned && !pc.faces_sphere) culled = true;

@@ -14,7 +14,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench  # noqa: E402  (bench.py's CONFIG_CASES: BASELINE's other configurations at the sizes it names)
+import bench  # noqa: E402  (bench.py's CONFIG_CASES: the benchmark's other configurations at the sizes it names)
 import raytracer_amd as rt  # noqa: E402
 from raytracer_amd import scenes  # noqa: E402
 
