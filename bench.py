@@ -49,8 +49,9 @@ beside the next frame's rendering (raytracer_amd/sharding.py); a rank sends the 
 more than the row's background and one background pixel a row, rank 0 rebuilds whole rows ("gather"
 in the line names the columns and the bytes a peer sends a frame).  --graph: a rank's frame (render through the
 allocation-free entry point, then the pack of its kept columns) is captured once into a HIP graph and
-replayed per frame, the collective staying outside the graph (on this runtime a replay costs the host
-0.073 ms a frame against 0.055 ms for the plain launches, tools/host_overhead.py, so plain launches are the default).
+replayed per frame, the collective staying outside the graph (on this runtime a replay costs the host as much
+as the plain launches or more -- 0.073 against 0.055 ms a frame on one box, 0.053 against 0.052 on another,
+tools/host_overhead.py -- so plain launches are the default).
 Rehearsals on a one-GPU box: BENCH_FORCE_COLLECTIVE=1 runs the multi-rank loop with a one-rank RCCL group;
 BENCH_SHARE_GPUS=1 under torch.distributed.run lets several ranks share the GPU, with gloo in RCCL's place (the same
 control flow: every rank must make the same collective calls in the same order).

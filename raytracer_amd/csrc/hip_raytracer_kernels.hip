@@ -2891,7 +2891,7 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
     // (Under stream capture the launch leaves events alone: a graph's replays are ordered by the streams
     // they are launched on.)
     const bool uses_scratch = (vc.flags & AEHIP_FLAG_COUNT_RAYS) || takes_streamed_pass(b);
-    const bool capturing = stream_is_capturing(stream);
+    const bool capturing = uses_scratch && stream_is_capturing(stream);        // (asked only where the answer matters: a launch without scratch has no event to leave alone)
     // the fixed array of aehip_backend_trace_device_static is shared by every backend on the GPU: its users are
     // ordered by the GPU's event as well as by the backend's own
     hipEvent_t shared_event = nullptr;
@@ -3090,7 +3090,7 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
 
     // resource figures of the kernel just launched; queried once per kernel and backend, not per launch
     // (and not while a graph is being captured: the figures then stay those of the last launch outside capture)
-    if(func != b->attr_func && !capturing) {
+    if(func != b->attr_func && !stream_is_capturing(stream)) {
         hipFuncAttributes attr;
         if(hipFuncGetAttributes(&attr, func) == hipSuccess) {
             b->stats.vgprs = static_cast<uint32_t>(attr.numRegs);

@@ -2,9 +2,10 @@
 
 The entry point exists for callers that cannot call hipMalloc.  Two checks that equality with the
 allocating entry point alone would not give:
-  * the call is captured into a HIP graph (torch.cuda.graph, capture mode "global": a hipMalloc, a
-    synchronisation or any other call that capture forbids fails the capture) and the graph's replays
-    reproduce the allocating call's image bit for bit;
+  * the call is captured into a HIP graph (torch.cuda.graph, capture mode "thread_local": a hipMalloc, a
+    synchronisation or any other call that capture forbids, made by the capturing thread -- the one the
+    library's call runs on -- fails the capture; other threads of the test process are left out of it) and
+    the graph's replays reproduce the allocating call's image bit for bit;
   * free device memory is the same before and after plain calls.
 """
 import numpy as np
@@ -55,7 +56,7 @@ def test_static_call_captured_into_a_graph_replays_to_the_allocating_calls_bits(
         side = torch.cuda.Stream()
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
-        with torch.cuda.graph(graph, stream=side, capture_error_mode="global"):
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
             back.trace_device_static(out.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert bool((out == 0x55).all()), "the captured call ran instead of being recorded"
@@ -80,7 +81,7 @@ def test_a_timed_request_is_refused_under_capture():
         side = torch.cuda.Stream()
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
-        with torch.cuda.graph(graph, stream=side, capture_error_mode="global"):
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
             with pytest.raises(rt.HipRaytracerError, match="AEHIP_FLAG_NO_TIMING"):
                 back.trace_device_static(out.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
             out.add_(1)                 # (a graph needs a node)
