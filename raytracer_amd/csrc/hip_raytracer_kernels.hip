@@ -2613,7 +2613,20 @@ namespace {
 // slots, the unit queue's cursor), the radiance block of a window of strips, the per-pixel sums of
 // the window's finished blocks.  A backend's own (allocated by set-up, at most kScratchBudget) or,
 // for aehip_backend_trace_device_static, the fixed array below, one copy per GPU.
-constexpr size_t kScratchBudget = static_cast<size_t>(448) << 20;       // radiance + totals a backend allocates at most
+// Radiance + totals a backend allocates at most.  The GPU has 288 GB: a 3840x2160 frame at 64 or more samples per pixel
+// needs 6.5 GB for all its strips at once, and every window more is a launch pair more with a tail of its own (the
+// depth-50 scene at 3840x2160, 16 samples: 33.0 ms in the four windows 448 MiB gave it, 27.7 ms in one; the 10,000-sphere
+// scene 126 -> 121 ms).  AEHIP_SCRATCH_MIB in the environment sets another limit (tests of the window loop).
+constexpr size_t kScratchBudget = static_cast<size_t>(8192) << 20;
+inline size_t scratch_budget() {
+    const char *env = std::getenv("AEHIP_SCRATCH_MIB");
+    if(env && *env) {
+        char *end = nullptr;
+        const unsigned long long mib = std::strtoull(env, &end, 10);
+        if(end && *end == '\0' && mib >= 1ull && mib <= (1ull << 20)) return static_cast<size_t>(mib) << 20;
+    }
+    return kScratchBudget;
+}
 constexpr size_t kStaticScratchBytes = AEHIP_STATIC_SCRATCH_BYTES;
 constexpr size_t kScratchHeader = 256;                                  // counters, and alignment of what follows
 constexpr uint32_t kMaxStaticWindows = 4096;                           // windows a call through the static scratch may take
@@ -3414,7 +3427,7 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
     }
 
     // scratch of the streamed pass (see launch()): the radiance block and block totals of a window
-    // of strips, the whole band if it fits kScratchBudget
+    // of strips, the whole band if it fits scratch_budget()
     {
         b->params = p;                  // takes_streamed_pass() reads the request
         const bool wanted = takes_streamed_pass(b);
@@ -3427,7 +3440,7 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
             AEHIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b->stream_groups_per_cu, b->stream_func, kBlock, 0));
             const size_t strips = static_cast<size_t>((p.width + kTileW - 1) / kTileW) * ((p.row_count + 3u) / 4u);
             const size_t per_strip = scratch_bytes_per_strip(p.spp);
-            const size_t window = std::min(strips, std::max<size_t>(1, kScratchBudget / per_strip));
+            const size_t window = std::min(strips, std::max<size_t>(1, scratch_budget() / per_strip));
             const size_t need = window * per_strip;
             if(need > b->radiance_capacity) {
                 if(b->d_radiance) (void)hipFree(b->d_radiance);

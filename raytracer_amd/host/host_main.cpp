@@ -33,10 +33,10 @@ int run_raytracer(void *buffer) {
                 if(options.enabled("stats")) {
                     const aehip_stats st = gpu.stats();
                     std::fprintf(stderr,
-                                 "{\"backend\": \"hip\", \"width\": %u, \"height\": %u, \"paths\": %llu, \"rays\": %llu, \"lane_slots\": %llu, "
-                                 "\"kernel_ms\": %.4f, \"copy_ms\": %.4f, \"mpaths_per_s\": %.1f, \"vgprs\": %u, \"lds_bytes\": %u}\n",
-                                 width, height, static_cast<unsigned long long>(st.paths), static_cast<unsigned long long>(st.rays),
-                                 static_cast<unsigned long long>(st.lane_slots), st.kernel_ms, st.copy_ms,
+                                 "{\"backend\": \"hip\", \"width\": %u, \"height\": %u, \"paths\": %llu, \"samples_walked\": %llu, \"rays\": %llu, "
+                                 "\"lane_slots\": %llu, \"kernel_ms\": %.4f, \"copy_ms\": %.4f, \"mpaths_per_s\": %.1f, \"vgprs\": %u, \"lds_bytes\": %u}\n",
+                                 width, height, static_cast<unsigned long long>(st.paths), static_cast<unsigned long long>(st.samples_walked),
+                                 static_cast<unsigned long long>(st.rays), static_cast<unsigned long long>(st.lane_slots), st.kernel_ms, st.copy_ms,
                                  st.kernel_ms > 0 ? static_cast<double>(st.paths) / (st.kernel_ms * 1e3) : 0.0, st.vgprs, st.lds_bytes);
                 }
                 return 0;
