@@ -3440,13 +3440,25 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
             AEHIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b->stream_groups_per_cu, b->stream_func, kBlock, 0));
             const size_t strips = static_cast<size_t>((p.width + kTileW - 1) / kTileW) * ((p.row_count + 3u) / 4u);
             const size_t per_strip = scratch_bytes_per_strip(p.spp);
-            const size_t window = std::min(strips, std::max<size_t>(1, scratch_budget() / per_strip));
-            const size_t need = window * per_strip;
-            if(need > b->radiance_capacity) {
+            size_t window = std::min(strips, std::max<size_t>(1, scratch_budget() / per_strip));
+            if(window * per_strip > b->radiance_capacity) {
                 if(b->d_radiance) (void)hipFree(b->d_radiance);
                 b->d_radiance = nullptr; b->radiance_capacity = 0;
-                AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_radiance), need));
-                b->radiance_capacity = need;
+                // A GPU shared with other work may not have the gigabytes a whole 4K frame's window takes: halve the
+                // window until the allocation fits (down to what 64 MiB hold) -- more windows, the same image
+                hipError_t e = hipErrorOutOfMemory;
+                for(;;) {
+                    e = hipMalloc(reinterpret_cast<void **>(&b->d_radiance), window * per_strip);
+                    if(e != hipErrorOutOfMemory || window * per_strip <= (static_cast<size_t>(64) << 20) || window == 1) break;
+                    (void)hipGetLastError();
+                    b->d_radiance = nullptr;
+                    window = (window + 1) / 2;
+                }
+                if(e != hipSuccess) {
+                    b->d_radiance = nullptr;
+                    return fail(AEHIP_E_HIP, "scratch of the streamed pass (%zu bytes): %s", window * per_strip, hipGetErrorString(e));
+                }
+                b->radiance_capacity = window * per_strip;
             }
             b->window_strips = static_cast<uint32_t>(window);
         } else {
