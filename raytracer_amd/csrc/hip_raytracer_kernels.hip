@@ -2209,27 +2209,57 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
             sum = f3{0.0f, 0.0f, 0.0f};
             hit = f3{0.0f, 0.0f, 0.0f};
             hits = 0;
-            for(uint32_t blk = share; blk < nblocks; blk += shares) {
-                const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
-                const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
-                if constexpr(ONE) {
-                    if(newton) {
-                        // The hit loop without a square root or a reciprocal (see kNewtonTolerance):
-                        // T = t / 2 of the previous cell takes one Newton step on
-                        //   f / 4 = dd T*T - h T + c / 4,   (f / 4)' = 2 dd T - h = -sqrt(disc) at the near root,
-                        // with rho ~ 1 / sqrt(disc) from its first-order expansion about the pixel's centre
-                        // (one add a cell).  Nine full-rate vector instructions a sample, eight where h is a row's
-                        // constant and seven where rho is too (SIDEWAYS and FLAT below); two rows
-                        // of equal length are walked side by side (they share u and u*u, and two
-                        // independent chains keep the vector unit fed: measured 21 clocks a sample
-                        // against 24 for one row at a time).
-                        struct newton_row {
-                            float v, h_row, dd_row, rho, T;
+            if constexpr(ONE) {
+                if(newton) {
+                    // The hit loop without a square root or a reciprocal (see kNewtonTolerance):
+                    // T = t / 2 of the previous cell takes one Newton step on
+                    //   f / 4 = dd T*T - h T + c / 4,   (f / 4)' = 2 dd T - h = -sqrt(disc) at the near root,
+                    // with rho ~ 1 / sqrt(disc) from its first-order expansion about the pixel's centre
+                    // (one add a cell).  Nine full-rate vector instructions a sample for a row on its own,
+                    // eight where h is a row's constant and seven where rho is too (SIDEWAYS and FLAT below).
+                    // Rows of equal length are walked side by side, four at a time where the share has them
+                    // (two, where it has two): they share u and u*u and the sum over the rows of T that
+                    // multiplies u, and independent chains keep the vector unit fed -- measured 21 clocks a
+                    // sample for two rows against 24 for one row at a time; four rows take 7.5 instructions
+                    // a sample where two take 8.  The rows are the share's, block after block: the order in
+                    // which a share's samples are added is free in this build.
+                    struct newton_row {
+                        float v, h_row, dd_row, rho, T;
+                    };
+                    // the share's rows of cells in sample order, one a call (false: none left)
+                    uint32_t next_blk = share, next_s = share * AEHIP_SAMPLE_BLOCK, next_end = min(vc.spp, next_s + AEHIP_SAMPLE_BLOCK);
+                    auto take_row = [&](cell_row &cr) {
+                        if(next_blk >= nblocks) return false;
+                        cr = row_at(next_s, next_end);
+                        next_s += cr.count;
+                        if(next_s >= next_end) {
+                            next_blk += shares;
+                            next_s = next_blk * AEHIP_SAMPLE_BLOCK;
+                            next_end = min(vc.spp, next_s + AEHIP_SAMPLE_BLOCK);
+                        }
+                        return true;
+                    };
+                    auto same_cells = [](const cell_row &a, const cell_row &b) {
+                        return a.count == b.count && a.first_cell == b.first_cell && a.cells == b.cells;
+                    };
+                    // (TWICE: some pixel of the strip needs a second step a cell -- newton_twice; the
+                    // others keep their first step's value, so a pixel's arithmetic does not depend on its neighbours)
+                    // (SIDEWAYS: the sphere's centre is off the camera's axis horizontally, so h = draw.oc
+                    // changes along a row; in the reference's scene it does not and is the row's constant)
+                    // (FLAT: every pixel of the strip may take 1 / sqrt(disc) as constant along a row --
+                    // newton_flat; such a pixel among others steps by zero, the same arithmetic)
+                    auto walk_rows = [&](auto twice_tag, auto sideways_tag, auto flat_tag) {
+                        constexpr bool TWICE = decltype(twice_tag)::value, SIDEWAYS = decltype(sideways_tag)::value, FLAT = decltype(flat_tag)::value;
+                        // where the rows of one shape start along u, and a row's own start: 1 / sqrt(disc) one cell
+                        // before its first cell, and T at the first cell (the first step refines it), both from
+                        // their expansions about the pixel's centre (newton_pixel)
+                        float du, u_first, drho;
+                        auto start_rows = [&](const cell_row &cr) {
+                            du = jitter ? vc.psx * cr.inv_cells : 0.0f;
+                            u_first = __builtin_fmaf(jitter ? (cr.first + off.rx) * cr.inv_cells : 0.5f, vc.psx, ux0);
+                            drho = newton_flat ? 0.0f : np.rho_u * du;
                         };
-                        // where a row starts: 1 / sqrt(disc) one cell before its first cell, and T at the
-                        // first cell (the first step refines it), both from their expansions about the
-                        // pixel's centre (newton_pixel, below)
-                        auto start_row = [&](const cell_row &cr, float u_first, float du) {
+                        auto start_row = [&](const cell_row &cr) {
                             newton_row nr;
                             nr.v = __builtin_fmaf(cr.jy, vc.psy, uy0);
                             nr.h_row = __builtin_fmaf(nr.v, cc.oc[1], dz * cc.oc[2]);
@@ -2240,97 +2270,131 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                             nr.T = __builtin_fmaf(np.T_u, off_u, __builtin_fmaf(np.T_v, off_v, np.T_c));
                             return nr;
                         };
-                        // (TWICE: some pixel of the strip needs a second step a cell -- newton_twice; the
-                        // others keep their first step's value, so a pixel's arithmetic does not depend on its neighbours)
-                        // (SIDEWAYS: the sphere's centre is off the camera's axis horizontally, so h = draw.oc
-                        // changes along a row; in the reference's scene it does not and is the row's constant)
-                        // (FLAT: every pixel of the strip may take 1 / sqrt(disc) as constant along a row --
-                        // newton_flat; such a pixel among others steps by zero, the same arithmetic)
-                        auto walk_rows = [&](auto twice_tag, auto sideways_tag, auto flat_tag) {
-                        constexpr bool TWICE = decltype(twice_tag)::value, SIDEWAYS = decltype(sideways_tag)::value, FLAT = decltype(flat_tag)::value;
-                        for(uint32_t s = s0; s < s1;) {
-                            const cell_row cr = row_at(s, s1);
-                            s += cr.count;
-                            const float du = jitter ? vc.psx * cr.inv_cells : 0.0f;
-                            const float u_first = __builtin_fmaf(jitter ? (cr.first + off.rx) * cr.inv_cells : 0.5f, vc.psx, ux0);
-                            float u = u_first - du;
-                            const float drho = newton_flat ? 0.0f : np.rho_u * du;
-                            newton_row ra = start_row(cr, u_first, du);
-                            bool pair = false;
-                            cell_row cr2 = cr;
-                            if(s < s1) {
-                                cr2 = row_at(s, s1);
-                                pair = cr2.count == cr.count && cr2.first_cell == cr.first_cell && cr2.cells == cr.cells;
+                        // a cell of a row: the step (two with TWICE) on the row's T
+                        auto step = [&](newton_row &r, float u, float uu) {
+                            if constexpr(!FLAT) r.rho += drho;
+                            const float dd = uu + r.dd_row;
+                            const float h = SIDEWAYS ? __builtin_fmaf(u, oc_x_v, r.h_row) : r.h_row;
+                            const float f4 = __builtin_fmaf(r.T, __builtin_fmaf(dd, r.T, -h), c4_v);
+                            r.T = __builtin_fmaf(f4, r.rho, r.T);
+                            if constexpr(TWICE) {
+                                const float g4 = __builtin_fmaf(r.T, __builtin_fmaf(dd, r.T, -h), c4_v);
+                                const float again = __builtin_fmaf(g4, r.rho, r.T);
+                                r.T = newton_twice ? again : r.T;
                             }
-                            if(pair) {
-                                s += cr2.count;
-                                newton_row rb = start_row(cr2, u_first, du);
-                                float scale_a = 0.0f, scale_b = 0.0f;
-#pragma unroll 2
-                                for(uint32_t k = 0; k < cr.count; k++) {
-                                    u += du;
-                                    if constexpr(!FLAT) {
-                                        ra.rho += drho;
-                                        rb.rho += drho;
-                                    }
-                                    const float uu = u * u;
-                                    const float dd_a = uu + ra.dd_row, dd_b = uu + rb.dd_row;
-                                    const float h_a = SIDEWAYS ? __builtin_fmaf(u, oc_x_v, ra.h_row) : ra.h_row, h_b = SIDEWAYS ? __builtin_fmaf(u, oc_x_v, rb.h_row) : rb.h_row;
-                                    const float f4_a = __builtin_fmaf(ra.T, __builtin_fmaf(dd_a, ra.T, -h_a), c4_v);
-                                    const float f4_b = __builtin_fmaf(rb.T, __builtin_fmaf(dd_b, rb.T, -h_b), c4_v);
-                                    ra.T = __builtin_fmaf(f4_a, ra.rho, ra.T);
-                                    rb.T = __builtin_fmaf(f4_b, rb.rho, rb.T);
-                                    if constexpr(TWICE) {
-                                        const float g4_a = __builtin_fmaf(ra.T, __builtin_fmaf(dd_a, ra.T, -h_a), c4_v);
-                                        const float g4_b = __builtin_fmaf(rb.T, __builtin_fmaf(dd_b, rb.T, -h_b), c4_v);
-                                        const float again_a = __builtin_fmaf(g4_a, ra.rho, ra.T), again_b = __builtin_fmaf(g4_b, rb.rho, rb.T);
-                                        ra.T = newton_twice ? again_a : ra.T;
-                                        rb.T = newton_twice ? again_b : rb.T;
-                                    }
-                                    scale_a += ra.T;
-                                    scale_b += rb.T;
-                                    hit.x = __builtin_fmaf(u, ra.T + rb.T, hit.x);
-                                }
-                                hit.y = __builtin_fmaf(ra.v, scale_a, __builtin_fmaf(rb.v, scale_b, hit.y));
-                                hit.z += scale_a + scale_b;
-                                hits += 2u * cr.count;
-                            } else {
-                                float row_scale = 0.0f;
-#pragma unroll 4
-                                for(uint32_t k = 0; k < cr.count; k++) {
-                                    u += du;
-                                    if constexpr(!FLAT) ra.rho += drho;
-                                    const float dd = __builtin_fmaf(u, u, ra.dd_row);
-                                    const float h = SIDEWAYS ? __builtin_fmaf(u, oc_x_v, ra.h_row) : ra.h_row;
-                                    const float f4 = __builtin_fmaf(ra.T, __builtin_fmaf(dd, ra.T, -h), c4_v);
-                                    ra.T = __builtin_fmaf(f4, ra.rho, ra.T);
-                                    if constexpr(TWICE) {
-                                        const float g4 = __builtin_fmaf(ra.T, __builtin_fmaf(dd, ra.T, -h), c4_v);
-                                        const float again = __builtin_fmaf(g4, ra.rho, ra.T);
-                                        ra.T = newton_twice ? again : ra.T;
-                                    }
-                                    hit.x = __builtin_fmaf(u, ra.T, hit.x);
-                                    row_scale += ra.T;
-                                }
-                                hit.y = __builtin_fmaf(ra.v, row_scale, hit.y);
-                                hit.z += row_scale;
-                                hits += cr.count;
-                            }
-                        }
                         };
-                        const bool twice = __ballot(newton_twice) != 0ull, flat = __ballot(!newton_flat) == 0ull;
-                        const std::true_type yes{};
-                        const std::false_type no{};
-                        if(cc.oc[0] != 0.0f) {
-                            if(twice) walk_rows(yes, yes, no);
-                            else if(flat) walk_rows(no, yes, yes);
-                            else walk_rows(no, yes, no);
-                        } else {
-                            if(twice) walk_rows(yes, no, no);
-                            else if(flat) walk_rows(no, no, yes);
-                            else walk_rows(no, no, no);
+                        auto walk_one = [&](const cell_row &cr) {
+                            start_rows(cr);
+                            newton_row ra = start_row(cr);
+                            float u = u_first - du, row_scale = 0.0f;
+#pragma unroll 4
+                            for(uint32_t k = 0; k < cr.count; k++) {
+                                u += du;
+                                if constexpr(!FLAT) ra.rho += drho;
+                                const float dd = __builtin_fmaf(u, u, ra.dd_row);
+                                const float h = SIDEWAYS ? __builtin_fmaf(u, oc_x_v, ra.h_row) : ra.h_row;
+                                const float f4 = __builtin_fmaf(ra.T, __builtin_fmaf(dd, ra.T, -h), c4_v);
+                                ra.T = __builtin_fmaf(f4, ra.rho, ra.T);
+                                if constexpr(TWICE) {
+                                    const float g4 = __builtin_fmaf(ra.T, __builtin_fmaf(dd, ra.T, -h), c4_v);
+                                    const float again = __builtin_fmaf(g4, ra.rho, ra.T);
+                                    ra.T = newton_twice ? again : ra.T;
+                                }
+                                hit.x = __builtin_fmaf(u, ra.T, hit.x);
+                                row_scale += ra.T;
+                            }
+                            hit.y = __builtin_fmaf(ra.v, row_scale, hit.y);
+                            hit.z += row_scale;
+                            hits += cr.count;
+                        };
+                        auto walk_two = [&](const cell_row &cr, const cell_row &cr2) {
+                            start_rows(cr);
+                            newton_row ra = start_row(cr), rb = start_row(cr2);
+                            float u = u_first - du, scale_a = 0.0f, scale_b = 0.0f;
+#pragma unroll 2
+                            for(uint32_t k = 0; k < cr.count; k++) {
+                                u += du;
+                                const float uu = u * u;
+                                step(ra, u, uu);
+                                step(rb, u, uu);
+                                scale_a += ra.T;
+                                scale_b += rb.T;
+                                hit.x = __builtin_fmaf(u, ra.T + rb.T, hit.x);
+                            }
+                            hit.y = __builtin_fmaf(ra.v, scale_a, __builtin_fmaf(rb.v, scale_b, hit.y));
+                            hit.z += scale_a + scale_b;
+                            hits += 2u * cr.count;
+                        };
+                        auto walk_four = [&](const cell_row &cr, const cell_row &cr2, const cell_row &cr3, const cell_row &cr4) {
+                            start_rows(cr);
+                            newton_row ra = start_row(cr), rb = start_row(cr2), rc = start_row(cr3), rd = start_row(cr4);
+                            float u = u_first - du, scale_a = 0.0f, scale_b = 0.0f, scale_c = 0.0f, scale_d = 0.0f;
+                            for(uint32_t k = 0; k < cr.count; k++) {
+                                u += du;
+                                const float uu = u * u;
+                                step(ra, u, uu);
+                                step(rb, u, uu);
+                                step(rc, u, uu);
+                                step(rd, u, uu);
+                                scale_a += ra.T;
+                                scale_b += rb.T;
+                                scale_c += rc.T;
+                                scale_d += rd.T;
+                                hit.x = __builtin_fmaf(u, (ra.T + rb.T) + (rc.T + rd.T), hit.x);
+                            }
+                            hit.y = __builtin_fmaf(ra.v, scale_a, __builtin_fmaf(rb.v, scale_b, __builtin_fmaf(rc.v, scale_c, __builtin_fmaf(rd.v, scale_d, hit.y))));
+                            hit.z += (scale_a + scale_b) + (scale_c + scale_d);
+                            hits += 4u * cr.count;
+                        };
+                        cell_row c0, c1, c2, c3, ahead;
+                        bool have = take_row(c0);
+                        while(have) {
+                            // up to three more rows of the same shape
+                            uint32_t n = 1u;
+                            bool more = take_row(ahead);
+                            if(more && same_cells(ahead, c0)) {
+                                c1 = ahead;
+                                n = 2u;
+                                more = take_row(ahead);
+                                if(!TWICE && more && same_cells(ahead, c0)) {
+                                    c2 = ahead;
+                                    n = 3u;
+                                    more = take_row(ahead);
+                                    if(more && same_cells(ahead, c0)) {
+                                        c3 = ahead;
+                                        n = 4u;
+                                        more = take_row(ahead);
+                                    }
+                                }
+                            }
+                            if constexpr(!TWICE) {
+                                if(n == 4u) walk_four(c0, c1, c2, c3);
+                            }
+                            if(n == 2u || n == 3u) walk_two(c0, c1);
+                            if(n == 1u) walk_one(c0);
+                            if(n == 3u) walk_one(c2);
+                            c0 = ahead;
+                            have = more;
                         }
+                    };
+                    const bool twice = __ballot(newton_twice) != 0ull, flat = __ballot(!newton_flat) == 0ull;
+                    const std::true_type yes{};
+                    const std::false_type no{};
+                    if(cc.oc[0] != 0.0f) {
+                        if(twice) walk_rows(yes, yes, no);
+                        else if(flat) walk_rows(no, yes, yes);
+                        else walk_rows(no, yes, no);
+                    } else {
+                        if(twice) walk_rows(yes, no, no);
+                        else if(flat) walk_rows(no, no, yes);
+                        else walk_rows(no, no, no);
                     }
+                }
+            }
+            for(uint32_t blk = share; blk < nblocks; blk += shares) {
+                const uint32_t s0 = blk * AEHIP_SAMPLE_BLOCK;
+                const uint32_t s1 = min(vc.spp, s0 + AEHIP_SAMPLE_BLOCK);
+                if constexpr(ONE) {
                     if(sure_hit) {
                         // The hit loop: every sample of the pixel hits at the near root (see the
                         // general loop below for the algebra).  Nine vector instructions a sample,

@@ -372,6 +372,22 @@ def test_newton_hit_loop_agrees_with_the_closed_form_and_the_exact_build(view, s
     assert float(np.abs(fast[..., :3] - exact[..., :3]).max()) <= 1e-5
 
 
+@pytest.mark.parametrize("spp", [72, 80, 88, 100, 104, 192, 512, 2048])
+def test_newton_hit_loop_with_every_grouping_of_rows(spp):
+    """The Newton hit loop walks a share's rows of cells four at a time, and what is left two at a
+    time or singly.  Rows of 8 cells (72 to 192 samples), whose last block holds one, two, three, four
+    (with a ragged row after them) or five rows; rows of 16 and of 32 (512, 2048 samples).  A band of
+    the 4K frame across the sphere, where the cells are fine enough for the loop at these counts:
+    every pixel within 1e-5 of the exact build, and of the same build with every sample walked
+    within the two arithmetics' rounding."""
+    kw = dict(spp=spp, max_depth=2, seed=11, jitter=True, row_begin=1000, row_count=160)
+    _, fast, _ = render_device(3840, 2160, fast=True, **kw)
+    _, fast_all, _ = render_device(3840, 2160, fast=True, walk_all=True, **kw)
+    _, exact, _ = render_device(3840, 2160, **kw)
+    assert float(np.abs(fast - fast_all).max()) <= 8e-6
+    assert float(np.abs(fast[..., :3] - exact[..., :3]).max()) <= 1e-5
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_random_single_sphere_views_fine_grids_fast_build_within_1e5_of_exact(seed):
     """Random single-sphere views at sizes and sample counts at which the fast build's hit loops run
