@@ -150,14 +150,14 @@ def executed_work(doc, key, seconds_per_frame, share=1.0):
         out["valu_lane_ops_per_s"] = lane_ops
         out["valu_issue_vs_measured_full_rate"] = lane_ops / VALU_FULL_RATE_MEASURED
         out["valu_issue_cycles_lower_bound_frac"] = slots / (SIMDS * SUSTAINED_CLOCK_HZ * seconds_per_frame)
+        # The shader clock of THIS run is not known here (2.0 GHz on a cold chip, 2.3-2.4 GHz in a settled run of the
+        # headline: tools/wave_timeline.py stamps it inside the kernel).  What is known: the clock below which the
+        # launch's vector instructions could not have issued in the time the launch took.
+        out["valu_issue_cycles_per_simd"] = slots / SIMDS
+        out["shader_clock_ghz_at_which_issue_would_fill_the_launch"] = slots / SIMDS / seconds_per_frame / 1e9
     if busy_us > 0.0:
-        # The chip does not hold 2.4 GHz under these kernels (2.1-2.35 GHz, lower the denser the FMAs): the
-        # datasheet peak scaled to the clock it did hold, and the issue bound at that clock
-        ghz = cycles / busy_us / 1e3
-        out["shader_clock_ghz"] = ghz
-        out["frac_of_fp32_peak_at_that_clock"] = out["tflops"] / (FP32_VECTOR_PEAK_TFLOPS * ghz / 2.4)
-        if valu > 0.0:
-            out["valu_issue_cycles_lower_bound_frac_at_that_clock"] = slots / (SIMDS * ghz * 1e9 * seconds_per_frame)
+        # clock of the COUNTER pass (profiled launches, no pre-warm): not this run's
+        out["counter_pass_shader_clock_ghz"] = cycles / busy_us / 1e3
     return out
 
 
@@ -480,9 +480,8 @@ def main():
                  "algorithmic_tflops": algorithmic, "vgprs": stats.vgprs, "lds_bytes": stats.lds_bytes}
             if ex:
                 r["work_reduction"] = algorithmic / ex["tflops"]
-                r["shader_clock_ghz"] = ex.get("shader_clock_ghz")
-                r["frac_of_fp32_peak_at_that_clock"] = ex.get("frac_of_fp32_peak_at_that_clock")
                 r["valu_issue_cycles_lower_bound_frac"] = ex.get("valu_issue_cycles_lower_bound_frac")
+                r["shader_clock_ghz_at_which_issue_would_fill_the_launch"] = ex.get("shader_clock_ghz_at_which_issue_would_fill_the_launch")
                 r["executed"] = ex
                 k = counters["workloads"][key]["kernels"].get(r["kernel"], {})
                 if "WRITE_SIZE" in k and "FETCH_SIZE" in k:

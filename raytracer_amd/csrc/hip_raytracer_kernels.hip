@@ -1657,21 +1657,22 @@ __global__ __launch_bounds__(256) void walked_pixels_kernel(view_consts vc, came
 
 #ifdef AEHIP_WAVE_TIMELINE
 // Measurement build (make timeline; tools/wave_timeline.py): every wave of the fast build's
-// single-sphere launch leaves its start and end on the constant-rate clock and whether it
-// rendered listed pixels, indexed by workgroup and wave (no atomics: they would serialise).
+// single-sphere launch leaves its start and end on the constant-rate clock, the shader clocks between
+// the two and whether it rendered listed pixels, indexed by workgroup and wave (no atomics: they would serialise).
 constexpr uint32_t kTimelineWaves = 1u << 18;
 __device__ unsigned long long g_timeline[kTimelineWaves * 3];
 __device__ unsigned int g_timeline_waves;
 struct timeline_stamp {
     unsigned long long t0;
     uint32_t kind;
+    unsigned long long c0 = __builtin_amdgcn_s_memtime();
     __device__ ~timeline_stamp() {
         if((threadIdx.x & 63u) == 0u) {
             const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
             if(i < kTimelineWaves) {
                 g_timeline[3u * i] = t0;
                 g_timeline[3u * i + 1u] = __builtin_amdgcn_s_memrealtime();
-                g_timeline[3u * i + 2u] = kind;
+                g_timeline[3u * i + 2u] = kind | ((__builtin_amdgcn_s_memtime() - c0) << 8);
             }
             if(i == 0u) g_timeline_waves = gridDim.x * (blockDim.x >> 6);
         }
@@ -2606,6 +2607,45 @@ __global__ __launch_bounds__(64) void row_miss_sums_kernel(view_consts vc, uint3
     out[y] = make_float4(sum.x, sum.y, sum.z, 0.0f);
 }
 
+// Fast build, one sphere: what each workgroup of the sphere's box will cost, for the order in which the launch
+// takes them (build_tile_order).  A wave's time does not depend on how many of its pixels walk a loop, only on
+// which loops it walks: the Newton loop with one step a cell, with 1 / sqrt(disc) constant along a row or not,
+// with two steps, the closed-form loop (weights: vector-unit clocks a sample, roughly); a workgroup lasts as long
+// as its longest wave.  One workgroup here for one of the launch's, in the box's own row-major order.
+__global__ __launch_bounds__(kBlock) void tile_cost_kernel(view_consts vc, camera_consts cc, uint32_t rows_per_group, uint32_t box_rows,
+                                                           uint32_t box_cols, uint32_t *__restrict__ cost) {
+    __shared__ uint32_t s_cost;
+    if(threadIdx.x == 0) s_cost = 0u;
+    __syncthreads();
+    const uint32_t width = box_cols >> 16, line = blockIdx.x / width;
+    const uint32_t gx = (box_cols & 0xffffu) + (blockIdx.x - line * width), gy = (box_rows & 0xffffu) + line;
+    const uint32_t strip = threadIdx.x >> 6, lane = threadIdx.x & 63u, strips = rows_per_group / 4u;
+    const uint32_t x = gx * kTileW + (lane & 15u), row = (gy * strips + strip) * 4u + (lane >> 4);
+    if(strip < strips) {
+        bool flat = false, once = false, twice = false, closed = false;
+        if(x < vc.width && row < vc.row_count) {
+            const pixel_class pc = classify_pixel(vc, cc, x, image_row(vc, row));
+            if(pc.may_hit && pc.well_conditioned) {         // (ill-conditioned pixels are the list's, not the box's)
+                if(cc.near_root_only == 0u) closed = true;  // the general loop: a square root and a reciprocal a hit, like the closed form
+                else if(pc.faces_sphere) {
+                    flat = pc.newton_flat_ok;
+                    once = !flat && pc.newton_ok;
+                    twice = !flat && !once && pc.newton_twice_ok;
+                    closed = !flat && !once && !twice;
+                }
+            }
+        }
+        uint32_t c = 0;
+        if(__ballot(twice) != 0ull) c += 24u;
+        else if(__ballot(once) != 0ull) c += 15u;
+        else if(__ballot(flat) != 0ull) c += 13u;
+        if(__ballot(closed) != 0ull) c += 40u;
+        if(lane == 0u) atomicMax(&s_cost, c);
+    }
+    __syncthreads();
+    if(threadIdx.x == 0) cost[blockIdx.x] = s_cost;
+}
+
 // The fast build's single-sphere launch when the band has ill-conditioned pixels: the first
 // list_groups workgroups render the listed pixels with the exact build's code up to the
 // discriminant (the reference's ray, normalisation and hit decision, bit for bit) and the fast
@@ -2623,7 +2663,8 @@ __global__ __launch_bounds__(kBlock, WALK ? 8 : 1) void camera_hybrid_kernel(vie
                                                                uint32_t *__restrict__ argb, float4 *__restrict__ rgba,
                                                                const uint32_t *__restrict__ pixel_list, uint32_t list_count,
                                                                uint32_t list_row_bias, uint32_t list_groups, uint32_t box_cols,
-                                                               uint32_t box_groups, uint32_t rows_per_group) {
+                                                               uint32_t box_groups, uint32_t rows_per_group,
+                                                               const uint32_t *__restrict__ tile_order) {
 #ifdef AEHIP_WAVE_TIMELINE
     timeline_stamp stamp{__builtin_amdgcn_s_memrealtime(), blockIdx.x < list_groups ? 1u : blockIdx.x - list_groups < box_groups ? 0u : 2u};
 #endif
@@ -2632,15 +2673,20 @@ __global__ __launch_bounds__(kBlock, WALK ? 8 : 1) void camera_hybrid_kernel(vie
                                                           list_count, list_row_bias, nullptr);
         return;
     }
-    // the box's workgroups (the whole grid when there is no box), rows in edges_first_row's order,
+    // the box's workgroups (the whole grid when there is no box) -- in set-up's order, the ones that last
+    // longest first (tile_order: column | row << 16), or else row by row in edges_first_row's order --
     // then the workgroups that fill the background around the box
     const uint32_t id = blockIdx.x - list_groups;
     if(id < box_groups) {
         const uint32_t width = box_cols >> 16;
         const uint32_t line = id / width;
-        const uint32_t gy = edges_first_row(line, row_order);
-        camera_body<false, true, false, AXIAL, true>(vc, cc, split_log2, nullptr, sample_terms, argb, rgba, (box_cols & 0xffffu) + (id - line * width),
-                                                     gy, nullptr, 0u, 0u, nullptr);
+        uint32_t gx = (box_cols & 0xffffu) + (id - line * width), gy = edges_first_row(line, row_order);
+        if(tile_order) {
+            const uint32_t t = __builtin_amdgcn_readfirstlane(tile_order[id]);
+            gx = t & 0xffffu;
+            gy = t >> 16;
+        }
+        camera_body<false, true, false, AXIAL, true>(vc, cc, split_log2, nullptr, sample_terms, argb, rgba, gx, gy, nullptr, 0u, 0u, nullptr);
     } else {
         fill_background(vc, id - box_groups, rows_per_group, row_order, box_cols, argb, rgba);
     }
@@ -2760,6 +2806,10 @@ struct aehip_backend {
     uint32_t *d_ring = nullptr;              // fast single-sphere camera pass: pixels the exact kernel redoes, sorted by band row
     uint32_t ring_capacity = 0, ring_count = 0;
     std::vector<uint32_t> ring_row_offset;   // entries before band row r (size rows + 1)
+    // fast single-sphere camera pass: the box's workgroups, longest first (build_tile_order), and the launch they are for
+    uint32_t *d_tile_order = nullptr;
+    uint32_t tile_order_capacity = 0, tile_order_count = 0;
+    uint32_t tile_order_box_rows = 0, tile_order_box_cols = 0, tile_order_rows_per_group = 0, tile_order_row_begin = 0, tile_order_row_count = 0;
     radiance3 *d_radiance = nullptr;         // streamed pass: a window's block of per-path radiance, then its
     size_t radiance_capacity = 0;            //   per-pixel sums of finished blocks; one allocation, size in bytes
     uint32_t window_strips = 0;              // strips of the band the allocation holds at the request's samples per pixel
@@ -2927,6 +2977,92 @@ bool sphere_box(const aehip_backend *b, const view_consts &vc, uint32_t rows_per
     return true;
 }
 
+// How a camera-pass launch over the band `vc` is laid out: waves a strip, rows a workgroup, the grid, the order of its rows.
+struct camera_layout {
+    uint32_t split_log2, rows_per_group, row_order, split_arg;
+    bool one, tiled, fold;
+    dim3 grid;
+};
+camera_layout camera_pass_layout(const aehip_backend *b, const view_consts &vc) {
+    camera_layout lay;
+    const bool exact = !(vc.flags & AEHIP_FLAG_FAST);
+    // waves per strip: as many as divide the pixel's sample blocks evenly (or nearly so)
+    const uint32_t nblocks = (vc.spp + AEHIP_SAMPLE_BLOCK - 1u) / AEHIP_SAMPLE_BLOCK;
+    lay.split_log2 = 0;
+    for(uint32_t l = 2; l >= 1; l--) {
+        const uint32_t waves = 1u << l;
+        if(nblocks % waves == 0 || nblocks >= 4u * waves) {
+            lay.split_log2 = l;
+            break;
+        }
+    }
+    // a sphere of (nearly) no radius has no usable 1/r: it goes through the list variant
+    lay.one = single_sphere_camera_pass(b);
+    // one sphere: a workgroup may cover a 16x16 tile, every wave a strip of its own (camera_body)
+    // (measured on the 4K 1024-sample frame, fast build: the whole frame 0.55 -> 0.49 ms and half of it,
+    // 4.1 M pixels, 0.316 -> 0.293 ms with tiles, a quarter 0.170 -> 0.174 ms, an eighth 0.101 -> 0.125 ms
+    // -- four times fewer, four times longer waves leave a short launch's tail emptier -- and the
+    // exact build, whose waves are long as it is, loses 7 % on the whole frame; with the workgroups in
+    // build_tile_order's order, cold clocks: whole frame 0.401 against 0.443 ms, half 0.220 / 0.232, a quarter
+    // 0.128 / 0.128, an eighth 0.083 / 0.076)
+    lay.tiled = lay.one && !exact && static_cast<uint64_t>(vc.width) * vc.row_count >= 4000000ull;
+    lay.rows_per_group = lay.tiled ? static_cast<uint32_t>(kTileH) : static_cast<uint32_t>(kTileH) >> lay.split_log2;
+    lay.grid = dim3((vc.width + kTileW - 1) / kTileW, (vc.row_count + lay.rows_per_group - 1) / lay.rows_per_group);
+    // the rows of workgroups in which the sphere can be hit, for the fast build's order of rows
+    // (edges_first_row; the exact build, whose strips cost much the same wherever they are, keeps plain order)
+    lay.row_order = lay.one && !exact && lay.grid.y <= 0xffffu ? sphere_group_rows(b, vc, lay.rows_per_group, lay.grid.y) : 1u;
+    // (oc.oc = c + r*r: the sphere's distance from the camera against its radius)
+    const bool exact_tail = lay.one && b->cc.c + b->cc.radius2 > kFastTailMaxDistance * kFastTailMaxDistance * b->cc.radius2;
+    lay.split_arg = lay.split_log2 | (lay.tiled ? kCameraTiled : 0u) | (exact_tail ? kCameraExactTail : 0u);
+    lay.fold = (vc.flags & kFlagFoldScreen) != 0;
+    return lay;
+}
+
+// Fast build, one sphere, a band with ill-conditioned pixels and a box: the order in which the launch over the whole
+// band takes the box's workgroups -- the ones that last longest first (tile_cost_kernel; ties in the box's row-major
+// order), those without a sample to walk last.  A launch ends when its last workgroup does, and workgroups last from
+// nothing (every pixel decided by its bounds) to 70 us (pixels of several classes): taken row by row, the 4K frame's
+// last workgroups were full-length ones on an emptying chip and the short ones sat between the long ones all through
+// the launch, each costing the dispatcher a slot (0.343 -> 0.323 ms a 1024-sample 4K frame).  Launches over part of
+// the band (aehip_backend_trace's) keep the row-by-row order.
+int build_tile_order(aehip_backend *b) {
+    const view_consts &vc = b->vc;
+    b->tile_order_count = 0;
+    if(!(vc.flags & AEHIP_FLAG_FAST) || (vc.flags & AEHIP_FLAG_WALK_ALL) || b->ring_row_offset.empty()) return AEHIP_OK;
+    const camera_layout lay = camera_pass_layout(b, vc);
+    uint32_t box_rows = 0, box_cols = 0;
+    if(!lay.one || lay.grid.x > 0xffffu || lay.grid.y > 0xffffu || !sphere_box(b, vc, lay.rows_per_group, lay.grid.x, lay.grid.y, &box_rows, &box_cols))
+        return AEHIP_OK;
+    const uint32_t width = box_cols >> 16, groups = width * ((box_rows >> 16) - (box_rows & 0xffffu) + 1u);
+    if(groups > b->tile_order_capacity) {
+        if(b->d_tile_order) (void)hipFree(b->d_tile_order);
+        b->d_tile_order = nullptr; b->tile_order_capacity = 0;
+        AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_tile_order), sizeof(uint32_t) * groups));
+        b->tile_order_capacity = groups;
+    }
+    hipLaunchKernelGGL(tile_cost_kernel, dim3(groups), dim3(kBlock), 0, b->stream, vc, b->cc, lay.rows_per_group, box_rows, box_cols, b->d_tile_order);
+    AEHIP_CHECK(hipGetLastError());
+    std::vector<uint32_t> cost(groups), order(groups);
+    AEHIP_CHECK(hipMemcpyAsync(cost.data(), b->d_tile_order, sizeof(uint32_t) * groups, hipMemcpyDeviceToHost, b->stream));
+    AEHIP_CHECK(hipStreamSynchronize(b->stream));
+    for(uint32_t i = 0; i < groups; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t l, uint32_t r) { return cost[l] > cost[r]; });
+    for(uint32_t i = 0; i < groups; i++) {
+        const uint32_t id = order[i], line = id / width;
+        cost[i] = ((box_cols & 0xffffu) + (id - line * width)) | (((box_rows & 0xffffu) + line) << 16);     // (cost[] is done with: reused for the packed order)
+    }
+    // (order[] held ids while cost[] was read by the comparator; the packed entries go out from cost[])
+    AEHIP_CHECK(hipMemcpyAsync(b->d_tile_order, cost.data(), sizeof(uint32_t) * groups, hipMemcpyHostToDevice, b->stream));
+    AEHIP_CHECK(hipStreamSynchronize(b->stream));
+    b->tile_order_count = groups;
+    b->tile_order_box_rows = box_rows;
+    b->tile_order_box_cols = box_cols;
+    b->tile_order_rows_per_group = lay.rows_per_group;
+    b->tile_order_row_begin = vc.row_begin;
+    b->tile_order_row_count = vc.row_count;
+    return AEHIP_OK;
+}
+
 // Clears the ray counters and the unit queue.  A kernel rather than hipMemsetAsync: under stream capture
 // the memset nodes of these 8- and 16-byte clears did not take effect on replay (the counters came back
 // with the array's old contents), while kernel nodes replay as launched.
@@ -3009,33 +3145,10 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         else if(vec4) { func = reinterpret_cast<const void *>(primary_kernel<false, true>); hipLaunchKernelGGL((primary_kernel<false, true>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba, box_rows, box_cols, bx0, bx1, by0, by1, compute_groups); }
         else { func = reinterpret_cast<const void *>(primary_kernel<false, false>); hipLaunchKernelGGL((primary_kernel<false, false>), grid, dim3(kPrimaryBlock), 0, stream, vc, b->cc, argb_dev, rgba, box_rows, box_cols, bx0, bx1, by0, by1, compute_groups); }
     } else if(b->all_terminal && vc.n_spheres <= static_cast<uint32_t>(kLdsSpheres)) {
-        // waves per strip: as many as divide the pixel's sample blocks evenly (or nearly so)
-        const uint32_t nblocks = (vc.spp + AEHIP_SAMPLE_BLOCK - 1u) / AEHIP_SAMPLE_BLOCK;
-        uint32_t split_log2 = 0;
-        for(uint32_t l = 2; l >= 1; l--) {
-            const uint32_t waves = 1u << l;
-            if(nblocks % waves == 0 || nblocks >= 4u * waves) {
-                split_log2 = l;
-                break;
-            }
-        }
-        // a sphere of (nearly) no radius has no usable 1/r: it goes through the list variant
-        const bool one = single_sphere_camera_pass(b);
-        // one sphere: a workgroup may cover a 16x16 tile, every wave a strip of its own (camera_body)
-        // (measured on the 4K 1024-sample frame, fast build: the whole frame 0.55 -> 0.49 ms and half of it,
-        // 4.1 M pixels, 0.316 -> 0.293 ms with tiles, a quarter 0.170 -> 0.174 ms, an eighth 0.101 -> 0.125 ms
-        // -- four times fewer, four times longer waves leave a short launch's tail emptier -- and the
-        // exact build, whose waves are long as it is, loses 7 % on the whole frame)
-        const bool tiled = one && !exact && static_cast<uint64_t>(vc.width) * vc.row_count >= 4000000ull;
-        const uint32_t rows_per_group = tiled ? static_cast<uint32_t>(kTileH) : static_cast<uint32_t>(kTileH) >> split_log2;
-        const dim3 grid((vc.width + kTileW - 1) / kTileW, (vc.row_count + rows_per_group - 1) / rows_per_group);
-        // the rows of workgroups in which the sphere can be hit, for the fast build's order of rows
-        // (edges_first_row; the exact build, whose strips cost much the same wherever they are, keeps plain order)
-        const uint32_t row_order = one && !exact && grid.y <= 0xffffu ? sphere_group_rows(b, vc, rows_per_group, grid.y) : 1u;
-        // (oc.oc = c + r*r: the sphere's distance from the camera against its radius)
-        const bool exact_tail = one && b->cc.c + b->cc.radius2 > kFastTailMaxDistance * kFastTailMaxDistance * b->cc.radius2;
-        const uint32_t split_arg = split_log2 | (tiled ? kCameraTiled : 0u) | (exact_tail ? kCameraExactTail : 0u);
-        const bool fold = (vc.flags & kFlagFoldScreen) != 0;
+        const camera_layout lay = camera_pass_layout(b, vc);
+        const uint32_t split_log2 = lay.split_log2, rows_per_group = lay.rows_per_group, row_order = lay.row_order, split_arg = lay.split_arg;
+        const bool one = lay.one, fold = lay.fold;
+        const dim3 grid = lay.grid;
 #define AEHIP_LAUNCH_CAMERA(E, O, F, A)                                                                                \
     do {                                                                                                               \
         func = reinterpret_cast<const void *>(camera_kernel<E, O, F, A>);                                              \
@@ -3072,12 +3185,17 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
                     fill_groups = grid.y * kFillSegments;
                 }
                 const dim3 line(list_groups + box_groups + fill_groups);
+                // set-up's order of the box's workgroups, if this launch is the one it was made for
+                const uint32_t *tile_order = fill_groups != 0 && b->tile_order_count == box_groups && b->tile_order_box_rows == box_rows &&
+                                                     b->tile_order_box_cols == box_cols && b->tile_order_rows_per_group == rows_per_group &&
+                                                     b->tile_order_row_begin == vc.row_begin && b->tile_order_row_count == vc.row_count
+                                                 ? b->d_tile_order : nullptr;
 #define AEHIP_LAUNCH_HYBRID(F, A, W)                                                                                   \
     do {                                                                                                               \
         func = reinterpret_cast<const void *>(camera_hybrid_kernel<F, A, W>);                                          \
         hipLaunchKernelGGL((camera_hybrid_kernel<F, A, W>), line, dim3(kBlock), 0, stream, vc, b->cc, split_arg, box_rows, \
                            b->d_sample_terms, argb_dev, rgba, b->d_ring + first, last - first, row0, list_groups, box_cols, \
-                           box_groups, rows_per_group);                                                                \
+                           box_groups, rows_per_group, tile_order);                                                    \
     } while(0)
                 const bool walk = (vc.flags & AEHIP_FLAG_WALK_ALL) != 0;
                 if(fold && axial) { if(walk) AEHIP_LAUNCH_HYBRID(true, true, true); else AEHIP_LAUNCH_HYBRID(true, true, false); }
@@ -3255,6 +3373,7 @@ void aehip_backend_destroy(aehip_backend *b) {
     if(b->d_camera) (void)hipFree(b->d_camera);
     if(b->d_prefilter) (void)hipFree(b->d_prefilter);
     if(b->d_ring) (void)hipFree(b->d_ring);
+    if(b->d_tile_order) (void)hipFree(b->d_tile_order);
     if(b->d_argb) (void)hipFree(b->d_argb);
     if(b->d_rays) (void)hipFree(b->d_rays);
     if(b->d_sample_terms) (void)hipFree(b->d_sample_terms);
@@ -3533,8 +3652,10 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
     // fast build, single-sphere camera pass: the pixels the exact kernel renders (ring_pixels_kernel)
     b->ring_count = 0;
     b->ring_row_offset.clear();
+    b->tile_order_count = 0;
     if((p.flags & AEHIP_FLAG_FAST) && p.pass == AEHIP_PASS_PATH && single_sphere_camera_pass(b)) {
-        const int rc = build_ring_list(b);
+        int rc = build_ring_list(b);
+        if(rc == AEHIP_OK) rc = build_tile_order(b);
         if(rc != AEHIP_OK) return rc;
     }
 
@@ -3874,7 +3995,7 @@ int load_rccl(rccl_api &api) {
 // Band i of n when the frame's rows are cut into tiles of tile_rows rows dealt round-robin: which
 // rows it has and where its rows start among the densely stored bands (band order).
 #ifdef AEHIP_WAVE_TIMELINE
-// out: 3 words a wave (start, end in 10 ns ticks; 0 = rendered a tile, 1 = listed pixels, 2 = filled background), at most `capacity` waves; returns the count
+// out: 3 words a wave (start, end in 10 ns ticks; low byte 0 = rendered a tile, 1 = listed pixels, 2 = filled background, above it the shader clocks between start and end), at most `capacity` waves; returns the count
 extern "C" int aehip_wave_timeline(unsigned long long *out, unsigned int capacity) {
     unsigned int n = 0;
     if(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_timeline_waves), sizeof(n)) != hipSuccess) return -1;

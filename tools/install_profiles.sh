@@ -10,6 +10,7 @@ for m in fast exact; do
         gpurun_out/${TAG}_scenes_$m/stress10k_4k_4spp_d4.txt gpurun_out/${TAG}_scenes_$m/divergence_4k_16spp_d50.txt > profiles/${NAME}_scenes_$m.txt
 done
 cp gpurun_out/${TAG}_primary/summary.txt profiles/${NAME}_primary.txt
+[ -f gpurun_out/${TAG}_wave_timeline.txt ] && grep -v amdgpu.ids gpurun_out/${TAG}_wave_timeline.txt > profiles/${NAME}_wave_timeline.txt
 [ -f gpurun_out/${TAG}_bench_line.json ] && cp gpurun_out/${TAG}_bench_line.json profiles/${NAME}_bench_line.json
 [ -f gpurun_out/${TAG}_bench_line_20_5.json ] && cp gpurun_out/${TAG}_bench_line_20_5.json profiles/${NAME}_bench_line_steps20_warmup5.json
 [ -f gpurun_out/${TAG}_bench_line_collective.json ] && cp gpurun_out/${TAG}_bench_line_collective.json profiles/${NAME}_bench_line_forced_collective.json

@@ -38,10 +38,14 @@ n = lib.aehip_wave_timeline(buf, cap)
 assert n > 0
 a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 3)[:n].astype(np.int64)
 t0 = a[:, 0].min()
-start, end, kind = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0, a[:, 2]        # microseconds
+start, end, kind, clocks = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0, a[:, 2] & 0xff, a[:, 2] >> 8        # microseconds
 dur = end - start
 span = end.max()
 print(f"{n} waves, launch {span:.1f} us (the stamps themselves cost a few per cent)")
+long_lived = dur > 20.0
+if long_lived.any():
+    ghz = clocks[long_lived] / dur[long_lived] / 1e3
+    print(f"shader clock over the waves that live more than 20 us: median {np.median(ghz):.3f} GHz, 5 % {np.percentile(ghz, 5):.3f}, 95 % {np.percentile(ghz, 95):.3f}")
 for k, name in ((1, "listed pixels"), (0, "rectangle"), (2, "background")):
     m = kind == k
     if m.any():
