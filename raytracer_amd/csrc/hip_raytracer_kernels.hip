@@ -2224,11 +2224,27 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                     // sample for two rows against 24 for one row at a time; four rows take 7.5 instructions
                     // a sample where two take 8.  The rows are the share's, block after block: the order in
                     // which a share's samples are added is free in this build.
+                    //
+                    // Where 1 / sqrt(disc) is a row's constant and h is too (FLAT, not SIDEWAYS) the step is
+                    // a polynomial in T with one coefficient that changes along the row:
+                    //   T + rho (T (dd T - h) + c / 4) = T ((rho dd) T + (1 - rho h)) + rho c / 4,
+                    // rho dd = rho u*u + rho dd_row one fused operation a cell, the other two coefficients the
+                    // row's: three operations a step instead of four (dd, two for the residual, T), 5.5
+                    // instructions a sample with four rows side by side.  Its roundings are of the size of
+                    // the other form's (each is a few unit roundoffs of c / (4 sqrt(disc))).  A pixel takes
+                    // this form when its own class says so, whatever its neighbours in the wave take: a
+                    // wave that holds both kinds walks the rows once for each (set-up's order of workgroups
+                    // counts such a wave at the sum and starts it early).
                     struct newton_row {
-                        float v, h_row, dd_row, rho, T;
+                        float v, h_row, dd_row, rho, T, C;      // (polynomial form: h_row holds 1 - rho h, dd_row holds rho dd_row, C rho c / 4)
                     };
                     // the share's rows of cells in sample order, one a call (false: none left)
-                    uint32_t next_blk = share, next_s = share * AEHIP_SAMPLE_BLOCK, next_end = min(vc.spp, next_s + AEHIP_SAMPLE_BLOCK);
+                    uint32_t next_blk = 0, next_s = 0, next_end = 0;
+                    auto first_row = [&]() {
+                        next_blk = share;
+                        next_s = share * AEHIP_SAMPLE_BLOCK;
+                        next_end = min(vc.spp, next_s + AEHIP_SAMPLE_BLOCK);
+                    };
                     auto take_row = [&](cell_row &cr) {
                         if(next_blk >= nblocks) return false;
                         cr = row_at(next_s, next_end);
@@ -2251,6 +2267,7 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                     // newton_flat; such a pixel among others steps by zero, the same arithmetic)
                     auto walk_rows = [&](auto twice_tag, auto sideways_tag, auto flat_tag) {
                         constexpr bool TWICE = decltype(twice_tag)::value, SIDEWAYS = decltype(sideways_tag)::value, FLAT = decltype(flat_tag)::value;
+                        constexpr bool POLY = FLAT && !SIDEWAYS && !TWICE;
                         // where the rows of one shape start along u, and a row's own start: 1 / sqrt(disc) one cell
                         // before its first cell, and T at the first cell (the first step refines it), both from
                         // their expansions about the pixel's centre (newton_pixel)
@@ -2269,10 +2286,20 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                             const float rho_column = __builtin_fmaf(np.rho_v, off_v, np.rho_c);        // in the pixel's middle column
                             nr.rho = newton_flat ? rho_column : __builtin_fmaf(np.rho_u, off_u - du, rho_column);
                             nr.T = __builtin_fmaf(np.T_u, off_u, __builtin_fmaf(np.T_v, off_v, np.T_c));
+                            nr.C = 0.0f;
+                            if constexpr(POLY) {
+                                nr.C = nr.rho * c4_v;
+                                nr.h_row = __builtin_fmaf(-nr.rho, nr.h_row, 1.0f);
+                                nr.dd_row = nr.rho * nr.dd_row;
+                            }
                             return nr;
                         };
                         // a cell of a row: the step (two with TWICE) on the row's T
                         auto step = [&](newton_row &r, float u, float uu) {
+                            if constexpr(POLY) {
+                                r.T = __builtin_fmaf(r.T, __builtin_fmaf(__builtin_fmaf(r.rho, uu, r.dd_row), r.T, r.h_row), r.C);
+                                return;
+                            }
                             if constexpr(!FLAT) r.rho += drho;
                             const float dd = uu + r.dd_row;
                             const float h = SIDEWAYS ? __builtin_fmaf(u, oc_x_v, r.h_row) : r.h_row;
@@ -2291,6 +2318,12 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
 #pragma unroll 4
                             for(uint32_t k = 0; k < cr.count; k++) {
                                 u += du;
+                                if constexpr(POLY) {
+                                    step(ra, u, u * u);
+                                    hit.x = __builtin_fmaf(u, ra.T, hit.x);
+                                    row_scale += ra.T;
+                                    continue;
+                                }
                                 if constexpr(!FLAT) ra.rho += drho;
                                 const float dd = __builtin_fmaf(u, u, ra.dd_row);
                                 const float h = SIDEWAYS ? __builtin_fmaf(u, oc_x_v, ra.h_row) : ra.h_row;
@@ -2348,6 +2381,7 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                             hits += 4u * cr.count;
                         };
                         cell_row c0, c1, c2, c3, ahead;
+                        first_row();
                         bool have = take_row(c0);
                         while(have) {
                             // up to three more rows of the same shape
@@ -2378,16 +2412,17 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                             have = more;
                         }
                     };
-                    const bool twice = __ballot(newton_twice) != 0ull, flat = __ballot(!newton_flat) == 0ull;
                     const std::true_type yes{};
                     const std::false_type no{};
                     if(cc.oc[0] != 0.0f) {
+                        const bool twice = __ballot(newton_twice) != 0ull, flat = __ballot(!newton_flat) == 0ull;
                         if(twice) walk_rows(yes, yes, no);
                         else if(flat) walk_rows(no, yes, yes);
                         else walk_rows(no, yes, no);
+                    } else if(newton_flat) {
+                        walk_rows(no, no, yes);
                     } else {
-                        if(twice) walk_rows(yes, no, no);
-                        else if(flat) walk_rows(no, no, yes);
+                        if(__ballot(newton_twice) != 0ull) walk_rows(yes, no, no);
                         else walk_rows(no, no, no);
                     }
                 }
@@ -2636,9 +2671,15 @@ __global__ __launch_bounds__(kBlock) void tile_cost_kernel(view_consts vc, camer
             }
         }
         uint32_t c = 0;
-        if(__ballot(twice) != 0ull) c += 24u;
-        else if(__ballot(once) != 0ull) c += 15u;
-        else if(__ballot(flat) != 0ull) c += 13u;
+        if(cc.oc[0] != 0.0f) {
+            if(__ballot(twice) != 0ull) c += 24u;
+            else if(__ballot(once) != 0ull) c += 15u;
+            else if(__ballot(flat) != 0ull) c += 15u;
+        } else {        // (flat pixels take the polynomial step in a walk of their own)
+            if(__ballot(twice) != 0ull) c += 24u;
+            else if(__ballot(once) != 0ull) c += 15u;
+            if(__ballot(flat) != 0ull) c += 11u;
+        }
         if(__ballot(closed) != 0ull) c += 40u;
         if(lane == 0u) atomicMax(&s_cost, c);
     }

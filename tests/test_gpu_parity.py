@@ -828,6 +828,19 @@ def test_headline_frame_is_the_same_on_1_2_4_8_gpus(fast):
         assert sha(render_tiled(w, h, world, 4, **kw)) == digest, f"{world} ranks"
 
 
+@pytest.mark.parametrize("world,tile_rows", [(3, 5), (2, 1), (4, 6), (2, 2)])
+def test_headline_frame_fast_build_is_the_same_in_tiles_that_cut_through_strips(world, tile_rows):
+    """A wave renders a strip of 16 x 4 pixels of its band.  With tiles of 1, 2, 5 or 6 rows a strip holds rows
+    from image rows that are no neighbours, so a pixel shares its wave with other pixels than in the frame one launch
+    renders -- pixels of other classes among them (the hit loop has a form of its own for pixels along whose rows
+    1 / sqrt(disc) is constant).  A pixel's arithmetic depends on its own class only: the fast build's frame at the
+    benchmark's size and sample count is bit for bit the same."""
+    w, h = 3840, 2160
+    kw = dict(spp=1024, max_depth=8, seed=1, jitter=True, fast=True)
+    whole, _ = rt.render(w, h, **kw)
+    assert sha(render_tiled(w, h, world, tile_rows, **kw)) == sha(whole)
+
+
 @pytest.mark.parametrize("world,tile_rows,size", [(2, 4, (128, 72)), (3, 5, (130, 75)), (4, 16, (100, 200)), (3, 1, (33, 47)),
                                                    (2, 1, (255, 3))])
 def test_tiled_bands_equal_the_whole_image(world, tile_rows, size):
