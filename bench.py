@@ -80,7 +80,7 @@ SUSTAINED_CLOCK_HZ = 2.32e9
 HBM_PEAK_GBS = 8000.0
 COUNTERS_FILE = os.path.join(ROOT, "profiles", "r03_counters.json")
 KERNEL_SOURCES = ["raytracer_amd/csrc/hip_raytracer_kernels.hip", "raytracer_amd/csrc/rt_exact_math.h"]
-SETUP_KERNELS = ("ring_pixels_kernel", "walked_pixels_kernel", "row_miss_sums_kernel")
+SETUP_KERNELS = ("ring_pixels_kernel", "walked_pixels_kernel", "row_miss_sums_kernel", "tile_cost_kernel")
 
 # the benchmark's other configurations at the sizes it names, shared with tools/bench_scenes.py (the counters'
 # workload keys are "<name>_<mode>"): name -> (width, height, spp, depth, seed, scene)

@@ -2609,14 +2609,22 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
     // and are filled in by the host.)
 }
 
-template <bool EXACT, bool ONE, bool FOLD, bool AXIAL>
+template <bool EXACT, bool ONE, bool FOLD, bool AXIAL, bool ORDERED = false>
 __global__ __launch_bounds__(kBlock) void camera_kernel(view_consts vc, camera_consts cc, uint32_t split_log2, uint32_t row_order,
                                                         const float4 *__restrict__ geom,
                                                         const uint32_t *__restrict__ sample_terms,
                                                         uint32_t *__restrict__ argb, float4 *__restrict__ rgba,
-                                                        const float4 *__restrict__ row_miss) {
-    camera_body<EXACT, ONE, FOLD, AXIAL, false>(vc, cc, split_log2, geom, sample_terms, argb, rgba, blockIdx.x,
-                                                edges_first_row(blockIdx.y, row_order), nullptr, 0u, 0u, row_miss);
+                                                        const float4 *__restrict__ row_miss, const uint32_t *__restrict__ tile_order) {
+    // (ORDERED: the grid's workgroups in set-up's order, tile_order: column | row << 16 -- build_tile_order)
+    uint32_t gx = blockIdx.x, gy = 0u;
+    if constexpr(ORDERED) {
+        const uint32_t t = __builtin_amdgcn_readfirstlane(tile_order[blockIdx.y * gridDim.x + blockIdx.x]);
+        gx = t & 0xffffu;
+        gy = t >> 16;
+    } else {
+        gy = edges_first_row(blockIdx.y, row_order);
+    }
+    camera_body<EXACT, ONE, FOLD, AXIAL, false>(vc, cc, split_log2, geom, sample_terms, argb, rgba, gx, gy, nullptr, 0u, 0u, row_miss);
 }
 
 // The exact build's value of a pixel whose samples all miss, before the division by spp: the row's
@@ -2642,25 +2650,30 @@ __global__ __launch_bounds__(64) void row_miss_sums_kernel(view_consts vc, uint3
     out[y] = make_float4(sum.x, sum.y, sum.z, 0.0f);
 }
 
-// Fast build, one sphere: what each workgroup of the sphere's box will cost, for the order in which the launch
-// takes them (build_tile_order).  A wave's time does not depend on how many of its pixels walk a loop, only on
-// which loops it walks: the Newton loop with one step a cell, with 1 / sqrt(disc) constant along a row or not,
-// with two steps, the closed-form loop (weights: vector-unit clocks a sample, roughly); a workgroup lasts as long
-// as its longest wave.  One workgroup here for one of the launch's, in the box's own row-major order.
-__global__ __launch_bounds__(kBlock) void tile_cost_kernel(view_consts vc, camera_consts cc, uint32_t rows_per_group, uint32_t box_rows,
-                                                           uint32_t box_cols, uint32_t *__restrict__ cost) {
+// One sphere: what each workgroup of a rectangle of the launch's grid (the sphere's box, or all of it) will cost,
+// for the order in which the launch takes them (build_tile_order).  A wave's time does not depend on how many of
+// its pixels walk a loop, only on which loops it walks.  Fast build: the Newton loop in its polynomial form, with
+// one step a cell, with two, the closed-form loop (weights: vector-unit clocks a sample, roughly).  Exact build:
+// the loop for waves of sure hits, or the general loop.  A workgroup lasts as long as its longest wave.  One
+// workgroup here for one of the launch's, in the rectangle's row-major order.
+__global__ __launch_bounds__(kBlock) void tile_cost_kernel(view_consts vc, camera_consts cc, uint32_t rows_per_group, uint32_t first_col,
+                                                           uint32_t first_row, uint32_t width, uint32_t exact, uint32_t *__restrict__ cost) {
     __shared__ uint32_t s_cost;
     if(threadIdx.x == 0) s_cost = 0u;
     __syncthreads();
-    const uint32_t width = box_cols >> 16, line = blockIdx.x / width;
-    const uint32_t gx = (box_cols & 0xffffu) + (blockIdx.x - line * width), gy = (box_rows & 0xffffu) + line;
+    const uint32_t line = blockIdx.x / width;
+    const uint32_t gx = first_col + (blockIdx.x - line * width), gy = first_row + line;
     const uint32_t strip = threadIdx.x >> 6, lane = threadIdx.x & 63u, strips = rows_per_group / 4u;
     const uint32_t x = gx * kTileW + (lane & 15u), row = (gy * strips + strip) * 4u + (lane >> 4);
     if(strip < strips) {
-        bool flat = false, once = false, twice = false, closed = false;
+        bool flat = false, once = false, twice = false, closed = false, sure = false, general = false;
         if(x < vc.width && row < vc.row_count) {
             const pixel_class pc = classify_pixel(vc, cc, x, image_row(vc, row));
-            if(pc.may_hit && pc.well_conditioned) {         // (ill-conditioned pixels are the list's, not the box's)
+            if(exact) {
+                // (camera_body, exact build: a wave all of whose pixels are sure hits takes the short loop)
+                sure = pc.may_hit && cc.short_exact_ok != 0u && pc.well_conditioned && pc.faces_sphere;
+                general = pc.may_hit && !sure;
+            } else if(pc.may_hit && pc.well_conditioned) {         // (ill-conditioned pixels are the list's, not the box's)
                 if(cc.near_root_only == 0u) closed = true;  // the general loop: a square root and a reciprocal a hit, like the closed form
                 else if(pc.faces_sphere) {
                     flat = pc.newton_flat_ok;
@@ -2671,7 +2684,10 @@ __global__ __launch_bounds__(kBlock) void tile_cost_kernel(view_consts vc, camer
             }
         }
         uint32_t c = 0;
-        if(cc.oc[0] != 0.0f) {
+        if(exact) {
+            if(__ballot(general) != 0ull) c = 150u;
+            else if(__ballot(sure) != 0ull) c = 135u;
+        } else if(cc.oc[0] != 0.0f) {
             if(__ballot(twice) != 0ull) c += 24u;
             else if(__ballot(once) != 0ull) c += 15u;
             else if(__ballot(flat) != 0ull) c += 15u;
@@ -3059,21 +3075,29 @@ camera_layout camera_pass_layout(const aehip_backend *b, const view_consts &vc) 
     return lay;
 }
 
-// Fast build, one sphere, a band with ill-conditioned pixels and a box: the order in which the launch over the whole
-// band takes the box's workgroups -- the ones that last longest first (tile_cost_kernel; ties in the box's row-major
-// order), those without a sample to walk last.  A launch ends when its last workgroup does, and workgroups last from
-// nothing (every pixel decided by its bounds) to 70 us (pixels of several classes): taken row by row, the 4K frame's
-// last workgroups were full-length ones on an emptying chip and the short ones sat between the long ones all through
-// the launch, each costing the dispatcher a slot (0.343 -> 0.323 ms a 1024-sample 4K frame).  Launches over part of
-// the band (aehip_backend_trace's) keep the row-by-row order.
+// One sphere: the order in which the launch over the whole band takes its workgroups -- the ones that last longest
+// first (tile_cost_kernel; ties in row-major order), those without a sample to walk last.  Fast build, a band with
+// ill-conditioned pixels: the workgroups of the sphere's box.  Exact build where it culls (the folded screening
+// ray): all of the grid.  A launch ends when its last workgroup does, and workgroups last from nothing (every pixel
+// decided by its bounds) to 70 us (fast build, pixels of several classes): taken row by row, the 4K frame's last
+// workgroups were full-length ones on an emptying chip and the short ones sat between the long ones all through the
+// launch, each costing the dispatcher a slot (fast: 0.343 -> 0.324 ms a 1024-sample 4K frame; exact: 4.29 -> 4.11 ms).
+// Launches over part of the band (aehip_backend_trace's) keep the row-by-row order.
 int build_tile_order(aehip_backend *b) {
     const view_consts &vc = b->vc;
     b->tile_order_count = 0;
-    if(!(vc.flags & AEHIP_FLAG_FAST) || (vc.flags & AEHIP_FLAG_WALK_ALL) || b->ring_row_offset.empty()) return AEHIP_OK;
+    if(b->params.pass != AEHIP_PASS_PATH || (vc.flags & AEHIP_FLAG_WALK_ALL) || !single_sphere_camera_pass(b)) return AEHIP_OK;
+    const bool exact = !(vc.flags & AEHIP_FLAG_FAST);
     const camera_layout lay = camera_pass_layout(b, vc);
+    if(lay.grid.x > 0xffffu || lay.grid.y > 0xffffu) return AEHIP_OK;
     uint32_t box_rows = 0, box_cols = 0;
-    if(!lay.one || lay.grid.x > 0xffffu || lay.grid.y > 0xffffu || !sphere_box(b, vc, lay.rows_per_group, lay.grid.x, lay.grid.y, &box_rows, &box_cols))
+    if(exact) {
+        if(!lay.fold) return AEHIP_OK;                      // (no table of all-miss sums: the pass culls nothing)
+        box_rows = (lay.grid.y - 1u) << 16;
+        box_cols = lay.grid.x << 16;
+    } else if(b->ring_row_offset.empty() || !sphere_box(b, vc, lay.rows_per_group, lay.grid.x, lay.grid.y, &box_rows, &box_cols)) {
         return AEHIP_OK;
+    }
     const uint32_t width = box_cols >> 16, groups = width * ((box_rows >> 16) - (box_rows & 0xffffu) + 1u);
     if(groups > b->tile_order_capacity) {
         if(b->d_tile_order) (void)hipFree(b->d_tile_order);
@@ -3081,7 +3105,8 @@ int build_tile_order(aehip_backend *b) {
         AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_tile_order), sizeof(uint32_t) * groups));
         b->tile_order_capacity = groups;
     }
-    hipLaunchKernelGGL(tile_cost_kernel, dim3(groups), dim3(kBlock), 0, b->stream, vc, b->cc, lay.rows_per_group, box_rows, box_cols, b->d_tile_order);
+    hipLaunchKernelGGL(tile_cost_kernel, dim3(groups), dim3(kBlock), 0, b->stream, vc, b->cc, lay.rows_per_group, box_cols & 0xffffu,
+                       box_rows & 0xffffu, width, exact ? 1u : 0u, b->d_tile_order);
     AEHIP_CHECK(hipGetLastError());
     std::vector<uint32_t> cost(groups), order(groups);
     AEHIP_CHECK(hipMemcpyAsync(cost.data(), b->d_tile_order, sizeof(uint32_t) * groups, hipMemcpyDeviceToHost, b->stream));
@@ -3092,7 +3117,6 @@ int build_tile_order(aehip_backend *b) {
         const uint32_t id = order[i], line = id / width;
         cost[i] = ((box_cols & 0xffffu) + (id - line * width)) | (((box_rows & 0xffffu) + line) << 16);     // (cost[] is done with: reused for the packed order)
     }
-    // (order[] held ids while cost[] was read by the comparator; the packed entries go out from cost[])
     AEHIP_CHECK(hipMemcpyAsync(b->d_tile_order, cost.data(), sizeof(uint32_t) * groups, hipMemcpyHostToDevice, b->stream));
     AEHIP_CHECK(hipStreamSynchronize(b->stream));
     b->tile_order_count = groups;
@@ -3192,10 +3216,23 @@ int launch(aehip_backend *b, uint32_t *argb_dev, float *rgba_dev, hipStream_t st
         const dim3 grid = lay.grid;
 #define AEHIP_LAUNCH_CAMERA(E, O, F, A)                                                                                \
     do {                                                                                                               \
-        func = reinterpret_cast<const void *>(camera_kernel<E, O, F, A>);                                              \
-        hipLaunchKernelGGL((camera_kernel<E, O, F, A>), grid, dim3(kBlock), 0, stream, vc, b->cc, split_arg, row_order, \
-                           b->d_geom, b->d_sample_terms, argb_dev, rgba, (E) && (O) && (F) && !(vc.flags & AEHIP_FLAG_WALK_ALL) ? b->d_row_miss : nullptr); \
+        if((E) && (O) && (F) && grid_order) {                                                                          \
+            func = reinterpret_cast<const void *>(camera_kernel<E, O, F, A, (E) && (O) && (F)>);                       \
+            hipLaunchKernelGGL((camera_kernel<E, O, F, A, (E) && (O) && (F)>), grid, dim3(kBlock), 0, stream, vc, b->cc, split_arg, row_order, \
+                               b->d_geom, b->d_sample_terms, argb_dev, rgba, b->d_row_miss, grid_order);               \
+        } else {                                                                                                       \
+            func = reinterpret_cast<const void *>(camera_kernel<E, O, F, A>);                                          \
+            hipLaunchKernelGGL((camera_kernel<E, O, F, A>), grid, dim3(kBlock), 0, stream, vc, b->cc, split_arg, row_order, \
+                               b->d_geom, b->d_sample_terms, argb_dev, rgba, (E) && (O) && (F) && !(vc.flags & AEHIP_FLAG_WALK_ALL) ? b->d_row_miss : nullptr, \
+                               static_cast<const uint32_t *>(nullptr));                                                \
+        }                                                                                                              \
     } while(0)
+        // set-up's order of the whole grid's workgroups (exact build), if this launch is the one it was made for
+        const uint32_t *grid_order = exact && !(vc.flags & AEHIP_FLAG_WALK_ALL) && b->tile_order_count == grid.x * grid.y &&
+                                             b->tile_order_box_cols == (grid.x << 16) && b->tile_order_box_rows == ((grid.y - 1u) << 16) &&
+                                             b->tile_order_rows_per_group == rows_per_group && b->tile_order_row_begin == vc.row_begin &&
+                                             b->tile_order_row_count == vc.row_count
+                                         ? b->d_tile_order : nullptr;
         // one ray per sample, whether the sample loop walks it or the pixel's bounds decide it; a
         // strip's 64 lanes are counted for each of its samples
         b->counts_known = true;
@@ -3695,8 +3732,7 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
     b->ring_row_offset.clear();
     b->tile_order_count = 0;
     if((p.flags & AEHIP_FLAG_FAST) && p.pass == AEHIP_PASS_PATH && single_sphere_camera_pass(b)) {
-        int rc = build_ring_list(b);
-        if(rc == AEHIP_OK) rc = build_tile_order(b);
+        const int rc = build_ring_list(b);
         if(rc != AEHIP_OK) return rc;
     }
 
@@ -3729,6 +3765,12 @@ int aehip_backend_setup(aehip_backend *b, const aehip_scene *scene, const aehip_
         }
         hipLaunchKernelGGL(row_miss_sums_kernel, dim3((p.height + 63u) / 64u), dim3(64), 0, b->stream, vc, p.height, b->d_row_miss);
         AEHIP_CHECK(hipGetLastError());
+    }
+
+    // single-sphere camera pass: the order in which a launch over the whole band takes its workgroups
+    {
+        const int rc = build_tile_order(b);
+        if(rc != AEHIP_OK) return rc;
     }
 
     // per-sample key terms
