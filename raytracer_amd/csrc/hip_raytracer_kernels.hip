@@ -3099,6 +3099,7 @@ int build_tile_order(aehip_backend *b) {
         return AEHIP_OK;
     }
     const uint32_t width = box_cols >> 16, groups = width * ((box_rows >> 16) - (box_rows & 0xffffu) + 1u);
+    if(groups > (1u << 22)) return AEHIP_OK;                // (16 MB of order and a sort of four million entries: beyond that, row by row)
     if(groups > b->tile_order_capacity) {
         if(b->d_tile_order) (void)hipFree(b->d_tile_order);
         b->d_tile_order = nullptr; b->tile_order_capacity = 0;
