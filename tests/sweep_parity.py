@@ -3,7 +3,7 @@
 oracle, every packed word, every averaged colour's bits and the ray count.  Prints one line per mismatch and a
 summary; exit status 1 if anything differed.  GPU only.
 
-    python tools/parity_sweep.py [--scenes 400] [--views 400] [--first 10000]
+    python tests/sweep_parity.py [--scenes 400] [--views 400] [--first 10000]
 """
 import argparse
 import json
@@ -14,7 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import oracle  # noqa: E402
 import raytracer_amd as rt  # noqa: E402
 from test_gpu_parity import random_scene, render_device  # noqa: E402
