@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copies what tools/profile_all.sh <tag> left under gpurun_out/ into profiles/ under the names DESIGN.md cites:
+# Copies what tools/profile_all.sh <tag> left under gpurun_out/ into profiles/ under the names the committed summaries carry:
 #   tools/install_profiles.sh <tag in gpurun_out> <name under profiles/>      e.g.  tools/install_profiles.sh r03b r03_b
 set -e
 TAG=$1; NAME=$2
