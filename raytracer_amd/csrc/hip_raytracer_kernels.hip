@@ -3103,7 +3103,11 @@ int build_tile_order(aehip_backend *b) {
     if(groups > b->tile_order_capacity) {
         if(b->d_tile_order) (void)hipFree(b->d_tile_order);
         b->d_tile_order = nullptr; b->tile_order_capacity = 0;
-        AEHIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_tile_order), sizeof(uint32_t) * groups));
+        if(hipMalloc(reinterpret_cast<void **>(&b->d_tile_order), sizeof(uint32_t) * groups) != hipSuccess) {
+            (void)hipGetLastError();        // (the order is an optimisation: without it the launch goes row by row)
+            b->d_tile_order = nullptr;
+            return AEHIP_OK;
+        }
         b->tile_order_capacity = groups;
     }
     hipLaunchKernelGGL(tile_cost_kernel, dim3(groups), dim3(kBlock), 0, b->stream, vc, b->cc, lay.rows_per_group, box_cols & 0xffffu,
