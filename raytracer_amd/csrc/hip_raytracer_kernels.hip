@@ -1527,7 +1527,7 @@ __device__ __forceinline__ pixel_class classify_pixel(const view_consts &vc, con
         // d disc / d u, linear in (u, v): largest at a corner
         slope_max = fmaxf(slope_max, fabsf(__builtin_fmaf(2.0f * cc.q_uu, u, __builtin_fmaf(cc.q_uv, v, cc.q_u))));
         // (and d disc / d v, in units of the step along u: the pixel is psy tall and psx wide)
-        slope_max = fmaxf(slope_max, fabsf(__builtin_fmaf(2.0f * cc.q_vv, v, __builtin_fmaf(cc.q_uv, u, cc.q_v))) * (vc.psy / vc.psx));
+        slope_max = fmaxf(slope_max, fabsf(__builtin_fmaf(2.0f * cc.q_vv, v, __builtin_fmaf(cc.q_uv, u, cc.q_v))) * (vc.psy * __builtin_amdgcn_rcpf(vc.psx)));
     }
     // smallest dd over the rectangle: each coordinate at its smallest magnitude
     const float ua = (u0 <= 0.0f && u0 + eu >= 0.0f) ? 0.0f : fminf(fabsf(u0), fabsf(u0 + eu));
@@ -1546,12 +1546,15 @@ __device__ __forceinline__ pixel_class classify_pixel(const view_consts &vc, con
     // Newton's step along a row of cells (see kNewtonTolerance): the widest cell of the pixel's grid
     // is a ragged last row's
     const uint32_t last_row_cells = vc.spp - (((vc.spp - 1u) >> vc.row_bits) << vc.row_bits);
-    const float du = jitter ? vc.psx / static_cast<float>(min(1u << vc.row_bits, last_row_cells)) : 0.0f;
-    const float s_min = __builtin_sqrtf(fmaxf(disc_min - pad, 0.0f));
-    const float ds = slope_max * du / (2.0f * s_min);                   // change of sqrt(disc) over a cell
-    const float t_max = cc.c / h_min;                                    // t = c / (h + sqrt(disc))
+    // (These are bounds with a factor to spare, compared with a tolerance: the hardware's reciprocal, reciprocal square
+    // root and square root -- an ulp off -- do for them what a dozen divisions and two square roots in full did, at a
+    // tenth of the instructions; s_min = 0, h_min <= 0, dd_min = 0 still end in inf or NaN and so in "no".)
+    const float du = jitter ? vc.psx * __builtin_amdgcn_rcpf(static_cast<float>(min(1u << vc.row_bits, last_row_cells))) : 0.0f;
+    const float inv_s_min = __builtin_amdgcn_rsqf(fmaxf(disc_min - pad, 0.0f));          // 1 / sqrt of the smallest discriminant
+    const float ds = slope_max * du * (0.5f * inv_s_min);               // change of sqrt(disc) over a cell
+    const float t_max = cc.c * __builtin_amdgcn_rcpf(h_min);             // t = c / (h + sqrt(disc))
     const float u_abs = fmaxf(fabsf(u0), fabsf(u0 + eu));
-    const float dt = (fabsf(cc.oc[0]) * du + ds + 2.0f * t_max * u_abs * du) / dd_min;
+    const float dt = (fabsf(cc.oc[0]) * du + ds + 2.0f * t_max * u_abs * du) * __builtin_amdgcn_rcpf(dd_min);
     // 1 / sqrt(disc) comes from its first-order expansion about the pixel's centre.  With
     // g = the relative change of disc across the pixel (2 cells ds / s_min along either axis;
     // slope_max covers both) the second-order term left out is 3/8 (g/2)^2 of it at an edge's
@@ -1559,21 +1562,22 @@ __device__ __forceinline__ pixel_class classify_pixel(const view_consts &vc, con
     // too (left out: about (t / (h + sqrt(disc))) (cells ds)^2 / (8 sqrt(disc)) an axis, under
     // g cells dt / 4), then takes a step like the others.
     const float cells = static_cast<float>(1u << vc.row_bits);
-    const float pixel_change = 2.0f * cells * ds / s_min;
+    const float pixel_change = 2.0f * cells * ds * inv_s_min;
     const float eps = 0.25f * pixel_change * pixel_change;
     const float start = dt + 0.25f * pixel_change * cells * dt;
-    const float t_error = 2.0f * (eps * start + start * start * dd_max / (2.0f * s_min));
+    const float curvature = dd_max * (0.5f * inv_s_min);                // dd / (2 sqrt(disc)): the step's second-order term is this times dt*dt
+    const float t_error = 2.0f * (eps * start + start * start * curvature);
     // colour = draw * (shade_scale * t) + constant; false for NaN (s_min = 0, h_min <= 0 give inf or a negative bound)
-    const float colour_per_t = cc.shade_scale * __builtin_sqrtf(dd_max);
+    const float colour_per_t = cc.shade_scale * __builtin_amdgcn_sqrtf(dd_max);
     const bool sane = h_min > 0.0f && cc.c > 0.0f && eps <= 0.05f;
     pc.newton_ok = sane && colour_per_t * t_error <= kNewtonTolerance;
     // a second step starts where the first ended (t_error carries a factor 2 to spare already)
-    const float t_error_twice = 2.0f * (eps * t_error + t_error * t_error * dd_max / (2.0f * s_min));
+    const float t_error_twice = 2.0f * (eps * t_error + t_error * t_error * curvature);
     pc.newton_twice_ok = sane && t_error <= 0.25f * start && colour_per_t * t_error_twice <= kNewtonTolerance;
     // with 1 / sqrt(disc) taken as constant along a row of cells (its value in the pixel's middle
     // column): off by its relative change across the pixel on top of the expansion's own error
-    const float eps_flat = eps + cells * ds / s_min;
-    pc.newton_flat_ok = pc.newton_ok && colour_per_t * 2.0f * (eps_flat * start + start * start * dd_max / (2.0f * s_min)) <= kNewtonTolerance;
+    const float eps_flat = eps + cells * ds * inv_s_min;
+    pc.newton_flat_ok = pc.newton_ok && colour_per_t * 2.0f * (eps_flat * start + start * start * curvature) <= kNewtonTolerance;
     return pc;
 }
 
