@@ -828,6 +828,35 @@ def test_headline_frame_is_the_same_on_1_2_4_8_gpus(fast):
         assert sha(render_tiled(w, h, world, 4, **kw)) == digest, f"{world} ranks"
 
 
+@pytest.mark.parametrize("fast", [True, False], ids=["fast", "exact"])
+def test_a_backend_set_up_again_for_other_bands_renders_them_as_a_fresh_one_does(fast):
+    """Set-up keeps per-band state on the device (the list of ill-conditioned pixels, the order in which a launch
+    takes its workgroups, the table of all-miss sums): one backend set up for a band, then for a larger one, then for
+    a smaller one of another frame size, renders each as a backend of its own does."""
+    import torch
+
+    flags = rt.FLAG_JITTER | (rt.FLAG_FAST if fast else 0)
+    bands = [((1920, 1080), dict(row_begin=300, row_count=200)), ((3840, 2160), dict(row_begin=0, row_count=2160)),
+             ((1280, 720), dict(row_begin=8, row_count=rt.band_row_count(720, 8, 4, 12), tile_rows=4, tile_stride=12)),
+             ((1920, 1080), dict(row_begin=0, row_count=1080))]
+    reused = rt.HipRaytracer(None)
+    try:
+        for (w, h), band in bands:
+            images = []
+            for back in (reused, rt.HipRaytracer(None)):
+                assert back.setup(w, h, 64, 8, 5, flags, rt.PASS_PATH, **band), back.last_error()
+                argb = torch.zeros((band["row_count"], w), dtype=torch.int32, device="cuda")
+                back.trace_device(argb.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                images.append(argb.cpu().numpy())
+                if back is not reused:
+                    back.close()
+            np.testing.assert_array_equal(images[0], images[1])
+            assert int((images[0] == 0).sum()) == 0          # every pixel written (alpha is 255)
+    finally:
+        reused.close()
+
+
 @pytest.mark.parametrize("world,tile_rows", [(3, 5), (2, 1), (4, 6), (2, 2)])
 def test_headline_frame_fast_build_is_the_same_in_tiles_that_cut_through_strips(world, tile_rows):
     """A wave renders a strip of 16 x 4 pixels of its band.  With tiles of 1, 2, 5 or 6 rows a strip holds rows
