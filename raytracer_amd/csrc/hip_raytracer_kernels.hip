@@ -2395,7 +2395,7 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                                 c1 = ahead;
                                 n = 2u;
                                 more = take_row(ahead);
-                                if(!TWICE && more && same_cells(ahead, c0)) {
+                                if(FLAT && more && same_cells(ahead, c0)) {
                                     c2 = ahead;
                                     n = 3u;
                                     more = take_row(ahead);
@@ -2406,7 +2406,10 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                                     }
                                 }
                             }
-                            if constexpr(!TWICE) {
+                            // (Four rows at a time for flat pixels, two for the others, whether these take a second
+                            // step or not: the order in which a pixel's samples are added follows from its own class,
+                            // not from what else is in its wave.  With a second step four rows take 82 registers.)
+                            if constexpr(FLAT) {
                                 if(n == 4u) walk_four(c0, c1, c2, c3);
                             }
                             if(n == 2u || n == 3u) walk_two(c0, c1);
@@ -2418,16 +2421,20 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                     };
                     const std::true_type yes{};
                     const std::false_type no{};
-                    if(cc.oc[0] != 0.0f) {
-                        const bool twice = __ballot(newton_twice) != 0ull, flat = __ballot(!newton_flat) == 0ull;
-                        if(twice) walk_rows(yes, yes, no);
-                        else if(flat) walk_rows(no, yes, yes);
-                        else walk_rows(no, yes, no);
-                    } else if(newton_flat) {
-                        walk_rows(no, no, yes);
+                    // flat pixels in a walk of their own, the others in theirs (with the second step if one of them takes it)
+                    const bool sideways = cc.oc[0] != 0.0f;
+                    if(newton_flat) {
+                        if(sideways) walk_rows(no, yes, yes);
+                        else walk_rows(no, no, yes);
                     } else {
-                        if(__ballot(newton_twice) != 0ull) walk_rows(yes, no, no);
-                        else walk_rows(no, no, no);
+                        const bool twice = __ballot(newton_twice) != 0ull;
+                        if(sideways) {
+                            if(twice) walk_rows(yes, yes, no);
+                            else walk_rows(no, yes, no);
+                        } else {
+                            if(twice) walk_rows(yes, no, no);
+                            else walk_rows(no, no, no);
+                        }
                     }
                 }
             }
@@ -2691,14 +2698,10 @@ __global__ __launch_bounds__(kBlock) void tile_cost_kernel(view_consts vc, camer
         if(exact) {
             if(__ballot(general) != 0ull) c = 150u;
             else if(__ballot(sure) != 0ull) c = 135u;
-        } else if(cc.oc[0] != 0.0f) {
+        } else {        // (flat pixels in a walk of their own: the polynomial step where the sphere's centre is in the camera's vertical plane)
             if(__ballot(twice) != 0ull) c += 24u;
-            else if(__ballot(once) != 0ull) c += 15u;
-            else if(__ballot(flat) != 0ull) c += 15u;
-        } else {        // (flat pixels take the polynomial step in a walk of their own)
-            if(__ballot(twice) != 0ull) c += 24u;
-            else if(__ballot(once) != 0ull) c += 15u;
-            if(__ballot(flat) != 0ull) c += 11u;
+            else if(__ballot(once) != 0ull) c += 16u;
+            if(__ballot(flat) != 0ull) c += cc.oc[0] != 0.0f ? 15u : 11u;
         }
         if(__ballot(closed) != 0ull) c += 40u;
         if(lane == 0u) atomicMax(&s_cost, c);

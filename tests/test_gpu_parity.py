@@ -862,12 +862,38 @@ def test_headline_frame_fast_build_is_the_same_in_tiles_that_cut_through_strips(
     """A wave renders a strip of 16 x 4 pixels of its band.  With tiles of 1, 2, 5 or 6 rows a strip holds rows
     from image rows that are no neighbours, so a pixel shares its wave with other pixels than in the frame one launch
     renders -- pixels of other classes among them (the hit loop has a form of its own for pixels along whose rows
-    1 / sqrt(disc) is constant).  A pixel's arithmetic depends on its own class only: the fast build's frame at the
-    benchmark's size and sample count is bit for bit the same."""
+    1 / sqrt(disc) is constant, and a second step for some).  A pixel's arithmetic, and the order in which its samples
+    are added, depend on its own class only: the fast build's frame at the benchmark's size and sample count is the
+    same bit for bit -- the averaged colours as floats, not only the packed words, which would hide all but one
+    difference in ten thousand."""
+    from raytracer_amd.sharding import band_image_rows, tiled_band
+
     w, h = 3840, 2160
     kw = dict(spp=1024, max_depth=8, seed=1, jitter=True, fast=True)
-    whole, _ = rt.render(w, h, **kw)
-    assert sha(render_tiled(w, h, world, tile_rows, **kw)) == sha(whole)
+    whole_argb, whole_rgba, _ = render_device(w, h, **kw)
+    for rank in range(world):
+        band = tiled_band(h, world, rank, tile_rows)
+        rows = band_image_rows(band)
+        argb, rgba, _ = render_device(w, h, **dict(kw, **band))
+        np.testing.assert_array_equal(argb, whole_argb[rows])
+        np.testing.assert_array_equal(rgba.view(np.uint32), whole_rgba[rows].view(np.uint32))
+
+
+@pytest.mark.parametrize("world,tile_rows,spp", [(2, 1, 1024), (3, 5, 256), (2, 3, 512)])
+def test_off_axis_frame_fast_build_is_the_same_in_tiles_that_cut_through_strips(world, tile_rows, spp):
+    """The same with the camera off the sphere's axis (the hit loops' variants with h = d.oc changing along a row):
+    floats and packed words of every band equal the single launch's."""
+    from raytracer_amd.sharding import band_image_rows, tiled_band
+
+    w, h = 2560, 1440
+    kw = dict(spp=spp, max_depth=8, seed=4, jitter=True, fast=True, cam=(0.6, 0.3, 1.4))
+    whole_argb, whole_rgba, _ = render_device(w, h, **kw)
+    for rank in range(world):
+        band = tiled_band(h, world, rank, tile_rows)
+        rows = band_image_rows(band)
+        argb, rgba, _ = render_device(w, h, **dict(kw, **band))
+        np.testing.assert_array_equal(argb, whole_argb[rows])
+        np.testing.assert_array_equal(rgba.view(np.uint32), whole_rgba[rows].view(np.uint32))
 
 
 @pytest.mark.parametrize("world,tile_rows,size", [(2, 4, (128, 72)), (3, 5, (130, 75)), (4, 16, (100, 200)), (3, 1, (33, 47)),
