@@ -933,6 +933,31 @@ def test_random_band_splits_equal_the_whole_image(seed):
     np.testing.assert_array_equal(render_tiled(w, h, world, tile_rows, **kw), whole)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_random_band_splits_equal_the_whole_image_as_floats(seed):
+    """The same property one level down: the averaged colours before quantisation, bit for bit, for random sizes,
+    tile heights, scenes and both builds -- larger frames and sample counts than above, so that every loop of the
+    camera pass is met (a float that depended on a pixel's neighbours would change a packed word only once in ten
+    thousand pixels)."""
+    from raytracer_amd.sharding import band_image_rows, tiled_band
+
+    rng = np.random.default_rng(9500 + seed)
+    w, h = int(rng.integers(300, 1400)), int(rng.integers(200, 800))
+    tile_rows = int(rng.choice([1, 2, 3, 4, 5, 8, 16]))
+    world = int(rng.integers(2, 5))
+    spheres = [None, None, scenes.showcase_scene(), scenes.divergence_scene()][seed % 4]
+    cam = (0.0, 0.0, 1.0) if seed % 8 < 4 else (float(rng.uniform(-0.8, 0.8)), float(rng.uniform(-0.4, 0.4)), 1.2)
+    kw = dict(spp=int(rng.choice([64, 256, 1024])) if spheres is None else int(rng.choice([3, 9, 66])), max_depth=int(rng.choice([2, 5])),
+              seed=seed, jitter=True, fast=bool((seed // 4) % 2), spheres=spheres, cam=cam)
+    whole_argb, whole_rgba, _ = render_device(w, h, **kw)
+    for rank in range(world):
+        band = tiled_band(h, world, rank, tile_rows)
+        rows = band_image_rows(band)
+        argb, rgba, _ = render_device(w, h, **dict(kw, **band))
+        np.testing.assert_array_equal(argb, whole_argb[rows])
+        np.testing.assert_array_equal(rgba.view(np.uint32), whole_rgba[rows].view(np.uint32))
+
+
 def test_setup_rejects_bad_tile_requests():
     back = rt.HipRaytracer(None)
     try:
