@@ -2222,12 +2222,13 @@ __device__ __forceinline__ void camera_body(const view_consts &vc, const camera_
                     // with rho ~ 1 / sqrt(disc) from its first-order expansion about the pixel's centre
                     // (one add a cell).  Nine full-rate vector instructions a sample for a row on its own,
                     // eight where h is a row's constant and seven where rho is too (SIDEWAYS and FLAT below).
-                    // Rows of equal length are walked side by side, four at a time where the share has them
-                    // (two, where it has two): they share u and u*u and the sum over the rows of T that
+                    // Rows of equal length are walked side by side -- four at a time for flat pixels where the
+                    // share has them, else two: they share u and u*u and the sum over the rows of T that
                     // multiplies u, and independent chains keep the vector unit fed -- measured 21 clocks a
                     // sample for two rows against 24 for one row at a time; four rows take 7.5 instructions
                     // a sample where two take 8.  The rows are the share's, block after block: the order in
-                    // which a share's samples are added is free in this build.
+                    // which a share's samples are added is free in this build, as long as it is the same
+                    // whatever else is in the pixel's wave (see where the rows are grouped, below).
                     //
                     // Where 1 / sqrt(disc) is a row's constant and h is too (FLAT, not SIDEWAYS) the step is
                     // a polynomial in T with one coefficient that changes along the row:
@@ -2716,7 +2717,7 @@ __global__ __launch_bounds__(kBlock) void tile_cost_kernel(view_consts vc, camer
 // arithmetic after it, the others the rectangle in the fast arithmetic minus those pixels.  One launch, so the few hundred list workgroups run beside the bulk instead of
 // on an empty chip (as a launch of their own they took 0.3 ms of a 2.2 ms 4K frame).
 // (No occupancy bound: held to the 64 vector registers of eight waves a SIMD the rectangle's body
-// spilled eight of them and rebuilt constants inside its row loop; with the 78 it takes, six
+// spilled eight of them and rebuilt constants inside its row loop; with the 77 to 79 it has taken since, six
 // waves, the 4K 1024-sample frame went from 0.433 to 0.408 ms.)
 // (WALK: the launch walks every sample of every pixel, AEHIP_FLAG_WALK_ALL -- the same code under a
 // bound of eight waves a SIMD, which the general loop's square roots and reciprocals want: 1.42
